@@ -1,0 +1,199 @@
+/*
+ * sknnr_hip.h -- C ABI of the MI355X (gfx950) backend for sknnr's
+ * kneighbors()/predict() hot path.
+ *
+ * Drop-in boundary: the reference has no FFI; everything its
+ * estimators need from the engine is behind two calls on a fitted
+ * sklearn.neighbors.KNeighborsRegressor,
+ *     RawKNNRegressor.kneighbors  -> super().kneighbors(X, n_neighbors, return_distance=True)
+ *                                    /root/reference/src/sknnr/_base.py:162-164
+ *     (inherited) predict         -> /root/reference/src/sknnr/_base.py:39, :346-348
+ * plus the transform that precedes them (_base.py:236-239) and the post-steps that
+ * follow them (_base.py:166-180).  Each entry point below names the reference
+ * interface it replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns
+ * SKNNR_OK (0) or a negative sknnr_status; sknnr_last_error() gives the message of
+ * the calling thread's last failure.  All matrices are row-major (C order) float64,
+ * indices are int64 -- exactly what the reference hands to / gets from scikit-learn.
+ * The caller owns every buffer it passes; the handle owns its device copies.
+ * One call at a time per handle.
+ */
+#ifndef SKNNR_HIP_H
+#define SKNNR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* The library is built with -fvisibility=hidden; exactly these declarations are exported. */
+#pragma GCC visibility push(default)
+
+#define SKNNR_ABI_VERSION 1
+
+typedef enum sknnr_status {
+    SKNNR_OK = 0,
+    SKNNR_ERR_INVALID = -1,     /* bad argument (message says which) */
+    SKNNR_ERR_K_TOO_LARGE = -2, /* n_neighbors > n_samples_fit: SKL/neighbors/_base.py:848-859 */
+    SKNNR_ERR_NO_TARGETS = -3,  /* predict without targets */
+    SKNNR_ERR_UNSUPPORTED = -4, /* outside the envelope of the HIP kernels (no CPU fallback exists) */
+    SKNNR_ERR_HIP = -5,         /* HIP runtime failure (message carries hipGetErrorString) */
+    SKNNR_ERR_NO_DEVICE = -6    /* no usable gfx950 device */
+} sknnr_status;
+
+/* Where the caller's query/output buffers live. */
+typedef enum sknnr_memspace {
+    SKNNR_MEM_HOST = 0,  /* ordinary host pointers; the library stages through PCIe */
+    SKNNR_MEM_DEVICE = 1 /* device pointers on the handle's GPU (e.g. torch tensor.data_ptr()) */
+} sknnr_memspace;
+
+/* Which float64 expression the reference's engine evaluates for a pair
+ * (SKL/neighbors/_base.py:620-648 picks the engine at fit time). */
+typedef enum sknnr_formula {
+    SKNNR_FORMULA_EXPANDED = 0, /* "brute"/ArgKmin: |x|^2 - 2 x.y + |y|^2, clamped at 0
+                                   (SKL/metrics/_pairwise_distances_reduction/_argkmin.pyx.tp:492-502) */
+    SKNNR_FORMULA_DIRECT = 1    /* "kd_tree" (D <= 15): sum (x - y)^2
+                                   (SKL/metrics/_dist_metrics.pxd.tp:39-57) */
+} sknnr_formula;
+
+typedef enum sknnr_weight_mode {
+    SKNNR_WEIGHTS_UNIFORM = 0,  /* np.mean over the k neighbours  (SKL/neighbors/_regression.py:254-255) */
+    SKNNR_WEIGHTS_DISTANCE = 1, /* 1/d, rows containing d == 0 become a 0/1 mask (SKL/neighbors/_base.py:113-119) */
+    SKNNR_WEIGHTS_EXPLICIT = 2  /* caller supplies w (nq, k): result of a Python callable on the distances */
+} sknnr_weight_mode;
+
+typedef struct sknnr_index sknnr_index; /* opaque handle */
+
+/* Per-call options of kneighbors/predict.  Zero-initialise, then set fields. */
+typedef struct sknnr_query_opts {
+    int32_t n_neighbors;   /* k of this call (reference: n_neighbors argument / ctor value) */
+    int32_t exclude_self;  /* 1 = the X=None path: the query rows ARE reference rows
+                              [row_offset, row_offset + nq); k+1 are searched and each row's own
+                              index is dropped (SKL/neighbors/_base.py:828-833, :936-963) */
+    int32_t deterministic; /* 1 = apply sknnr's tie-break reorder (REF _base.py:166-175) */
+    int32_t decimals;      /* RawKNNRegressor.DISTANCE_PRECISION_DECIMALS (REF _base.py:102), default 10 */
+    int32_t formula;       /* sknnr_formula */
+    int32_t apply_affine;  /* 1 = queries are untransformed (d_in columns) and the handle's affine map
+                              is applied first (REF _base.py:236-239); 0 = already transformed (d columns) */
+    int32_t weight_mode;   /* predict only: sknnr_weight_mode */
+    int32_t reserved;
+    int64_t row_offset;    /* position of query row 0 inside the logical call: key 2 of the reorder is
+                              |idx - row| with row counted over the whole call (REF _base.py:171), so a
+                              shard or chunk must carry its global offset */
+} sknnr_query_opts;
+
+/* Counters of the handle since creation (or the last reset). */
+typedef struct sknnr_stats {
+    int64_t queries;           /* query rows answered */
+    int64_t coarse_queries;    /* rows that went through the f16x3 MFMA pre-filter */
+    int64_t exact_fallbacks;   /* rows whose certificate failed and were re-scanned in float64 */
+    int64_t exact_only_queries;/* rows answered by the float64 scan alone (k or d outside the MFMA envelope) */
+    double  last_kernel_ms;    /* device time of the most recent call (hipEvent, launch stream) */
+    double  last_coarse_ms;    /* ... of which the MFMA pre-filter kernel */
+} sknnr_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* Number of visible HIP devices (0 if none).  Never fails. */
+int32_t sknnr_device_count(void);
+
+/* ABI version of the loaded library (== SKNNR_ABI_VERSION). */
+int32_t sknnr_abi_version(void);
+
+/* Message of this thread's last error ("" if none). */
+const char* sknnr_last_error(void);
+
+/*
+ * Build the device-resident index from the transformed reference rows.
+ * Replaces KNeighborsRegressor.fit -> NeighborsBase._fit storing _fit_X and _y
+ * (SKL/neighbors/_base.py:474-694; called from REF _base.py:107, :266-267).
+ *   ref   : host, (n_ref, d) transformed features (the reference's _fit_X)
+ *   y     : host, (n_ref, t) targets (the reference's _y) or NULL (kneighbors only)
+ *   device: HIP device ordinal
+ */
+int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, const double* y, int32_t t,
+                       int32_t device, sknnr_index** out);
+
+/* Free the handle and everything it owns.  NULL is allowed. */
+void sknnr_index_destroy(sknnr_index* index);
+
+/*
+ * Install the query-time feature transform X -> ((X - center) / scale) @ proj.
+ * Replaces transformer_.transform(X) (REF _base.py:236-239;
+ * transformers/_cca_transformer.py:87, _ccora_transformer.py:70,
+ * _mahalanobis_transformer.py:55, SKL/preprocessing/_data.py:1057-1098).
+ *   center, scale : host, (d_in) or NULL;  proj : host, (d_in, d) or NULL (then d_in == d).
+ */
+int sknnr_index_set_affine(sknnr_index* index, int32_t d_in, const double* center,
+                           const double* scale, const double* proj);
+
+/* Read back sizes: any pointer may be NULL. */
+int sknnr_index_shape(const sknnr_index* index, int64_t* n_ref, int32_t* d, int32_t* t,
+                      int32_t* d_in, int32_t* device);
+
+int sknnr_get_stats(const sknnr_index* index, sknnr_stats* out);
+int sknnr_reset_stats(sknnr_index* index);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/*
+ * k nearest reference rows of each query row.
+ * Replaces RawKNNRegressor.kneighbors (REF _base.py:111-182) = sklearn's
+ * KNeighborsMixin.kneighbors (SKL/neighbors/_base.py:763-963) + sknnr's reorder.
+ *   q        : (nq, d_in or d) float64 in `mem`, or NULL with opts->exclude_self = 1
+ *              (the query rows are then the handle's own reference rows)
+ *   out_dist : (nq, k) float64 in `mem`, ascending / reordered distances; may be NULL
+ *   out_idx  : (nq, k) int64 in `mem`, reference row indices
+ *   stream   : hipStream_t to launch on when mem == SKNNR_MEM_DEVICE (NULL = default stream);
+ *              ignored for host buffers (the call then returns after the copy-back)
+ */
+int sknnr_kneighbors(sknnr_index* index, const double* q, int64_t nq,
+                     const sknnr_query_opts* opts, double* out_dist, int64_t* out_idx,
+                     int32_t mem, void* stream);
+
+/*
+ * Weighted multi-output mean of the neighbours' targets.
+ * Replaces KNeighborsRegressor.predict (SKL/neighbors/_regression.py:224-268) as reached
+ * from REF _base.py:39 (X=None, independent prediction) and :346-348.
+ *   out_pred : (nq, t) float64 in `mem`
+ *   out_dist, out_idx : optional (nq, k) outputs of the underlying kneighbors (NULL to skip)
+ * With opts->weight_mode == SKNNR_WEIGHTS_EXPLICIT use sknnr_predict_from_neighbors instead.
+ */
+int sknnr_predict(sknnr_index* index, const double* q, int64_t nq, const sknnr_query_opts* opts,
+                  double* out_pred, double* out_dist, int64_t* out_idx, int32_t mem, void* stream);
+
+/*
+ * The reduction alone, from neighbours already found (needed when `weights` is a Python
+ * callable: the host evaluates it on the distances and passes w).
+ *   dist : (nq, k) or NULL for uniform;  idx : (nq, k);  w : (nq, k) for SKNNR_WEIGHTS_EXPLICIT
+ */
+int sknnr_predict_from_neighbors(sknnr_index* index, const double* dist, const int64_t* idx,
+                                 const double* w, int64_t nq, int32_t k, int32_t weight_mode,
+                                 double* out_pred, int32_t mem, void* stream);
+
+/*
+ * Dataframe-index crosswalk: out[i] = table[idx[i]].
+ * Replaces self.dataframe_index_in_[neigh_ind] (REF _base.py:177-180) for int64 plot IDs.
+ *   table : (n_table) int64 in `mem`;  idx, out : (n) int64 in `mem`
+ */
+int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int64_t* idx, int64_t n,
+                    int64_t* out, int32_t device, int32_t mem, void* stream);
+
+/* ---- diagnostics (used by the parity tests to validate the MFMA operand maps) ----------- */
+
+/*
+ * Full matrix of the pre-filter's approximate ranking values for a small problem:
+ *   out[i, j] ~= s^2 (|r_j - mu|^2 - 2 (q_i - mu).(r_j - mu))   float32, host (nq, n_ref)
+ * computed by the same MFMA sequence as the production kernel.  Also returns the scale s,
+ * the per-query |s (q_i - mu)|^2 (host, nq) and the error budget eps the certificate uses.
+ * q is host, already transformed (d columns).  nq * n_ref must be <= 2^24.
+ */
+int sknnr_debug_coarse_matrix(sknnr_index* index, const double* q, int64_t nq, float* out,
+                              double* out_qnorm, double* out_scale, double* out_eps);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKNNR_HIP_H */

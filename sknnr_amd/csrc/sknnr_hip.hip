@@ -1,0 +1,883 @@
+// sknnr_hip.hip -- the C ABI of include/sknnr_hip.h over the gfx950 kernels.
+//
+// Host side only: index construction (coarse image of the reference rows), workspace,
+// the per-chunk launch sequence  prep -> coarse (MFMA) -> finalize -> exact_scan,
+// staging for host buffers, error reporting.  No CPU path computes results: if a
+// device call fails the function fails.
+#include "../../include/sknnr_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "coarse.hip.h"
+#include "exact.hip.h"
+
+using namespace sknnr;
+
+// ----------------------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(SKNNR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// ----------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------
+namespace {
+
+// IEEE binary16 from double, round-to-nearest-even, overflow -> inf.
+uint16_t f64_to_f16_bits(double v) {
+    const float f = (float)v;  // double rounding is harmless: lo is taken from the actual hi
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t absx = x & 0x7fffffffu;
+    if (absx >= 0x7f800000u) return (uint16_t)(sign | (absx > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (absx >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // rounds to >= 65520 -> inf
+    if (absx < 0x33000001u) return (uint16_t)sign;               // < 2^-25 (or exactly) -> 0
+    int exp = (int)(absx >> 23) - 127;
+    uint32_t man = (absx & 0x7fffffu) | 0x800000u;  // 24-bit significand
+    int shift;                                        // bits to drop
+    uint32_t hexp;
+    if (exp < -14) {  // subnormal half
+        shift = 13 + (-14 - exp);
+        hexp = 0;
+    } else {
+        shift = 13;
+        hexp = (uint32_t)(exp + 15);
+    }
+    uint32_t q = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1u);
+    const uint32_t halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+    uint32_t out;
+    if (hexp == 0) out = q;  // q may reach 0x400 = smallest normal: encoding is continuous
+    else out = ((hexp - 1) << 10) + q;  // q in [0x400, 0x800]; carry bumps the exponent
+    return (uint16_t)(sign | out);
+}
+
+double f16_bits_to_f64(uint16_t h) {
+    const int sign = (h >> 15) & 1;
+    const int exp = (h >> 10) & 31;
+    const int man = h & 1023;
+    double v;
+    if (exp == 0) v = std::ldexp((double)man, -24);
+    else if (exp == 31) v = man ? std::numeric_limits<double>::quiet_NaN() : std::numeric_limits<double>::infinity();
+    else v = std::ldexp((double)(man | 1024), exp - 25);
+    return sign ? -v : v;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+constexpr int kListLen = 8;            // M of the production coarse kernel
+constexpr int kCoarseMaxKK = kListLen - 1;
+constexpr int kMaxKs = 8;              // coarse path: d <= 128
+constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk
+constexpr int kScanMaxKK = 192;
+// Error budget of the split contraction, in units of 2^-24 (|q'| + max|r'|)^2:
+// eps_units(ks) = 8 + 4 ks.  Measured worst case on gfx950 over 5e5 pairs per shape
+// (scripts/gpu_probe.py, tests/test_hip_parity.py::test_coarse_error_budget): 2.6 (d=8),
+// 3.4 (16), 3.8 (32), 3.9 (64), 5.1 (100) -- the budget keeps >= 4x headroom.
+constexpr double eps_units(int ks) { return 8.0 + 4.0 * ks; }
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
+// the handle
+// ----------------------------------------------------------------------------------------
+struct sknnr_index {
+    int device = 0;
+    long n_ref = 0;
+    int d = 0, t = 0;
+    int ks = 0;       // K-steps of the coarse image (0 = coarse path unavailable: d > 128)
+    int n_stages = 0;
+    double s = 1.0;   // coarse scale
+    double ymax = 0.0;
+    std::vector<double> mu;  // (16*ks) zero padded
+
+    // query-time affine map
+    int d_in = 0;
+    bool has_affine = false;
+    DevBuf<double> center, scale, proj;  // proj padded to (d_in, 16*ks) when ks > 0 else (d_in, d)
+    bool has_center = false, has_scale = false, has_proj = false;
+
+    DevBuf<double> ref64, rn64, y64, mu_dev;
+    DevBuf<char> rimg;
+
+    // workspace (one chunk)
+    DevBuf<double> xt, qnc, xstage, dist_stage, pred_stage;
+    DevBuf<uint4> qimg;
+    DevBuf<float> cand_val;
+    DevBuf<int> cand_idx, fail_list, fail_count;
+    DevBuf<long long> fail_total;  // running count of certificate failures (device)
+    DevBuf<long> idx_stage;
+
+    hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
+    sknnr_stats stats{};
+    bool timing_pending = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> coarse_events;
+    size_t coarse_events_used = 0;
+
+    ~sknnr_index() {
+        (void)hipSetDevice(device);
+        for (auto* b : {&center, &scale, &proj, &ref64, &rn64, &y64, &mu_dev, &xt, &qnc, &xstage,
+                        &dist_stage, &pred_stage})
+            b->release();
+        rimg.release();
+        qimg.release();
+        cand_val.release();
+        cand_idx.release();
+        fail_list.release();
+        fail_count.release();
+        fail_total.release();
+        idx_stage.release();
+        for (hipEvent_t e : {ev_call0, ev_call1, ev_c0, ev_c1})
+            if (e) (void)hipEventDestroy(e);
+        for (auto& pr : coarse_events) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------------------
+// misc entry points
+// ----------------------------------------------------------------------------------------
+extern "C" int32_t sknnr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int32_t sknnr_abi_version(void) { return SKNNR_ABI_VERSION; }
+
+extern "C" const char* sknnr_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int sknnr_index_shape(const sknnr_index* ix, int64_t* n_ref, int32_t* d, int32_t* t,
+                                 int32_t* d_in, int32_t* device) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    if (n_ref) *n_ref = ix->n_ref;
+    if (d) *d = ix->d;
+    if (t) *t = ix->t;
+    if (d_in) *d_in = ix->has_affine ? ix->d_in : ix->d;
+    if (device) *device = ix->device;
+    return SKNNR_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// index construction
+// ----------------------------------------------------------------------------------------
+extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, const double* y,
+                                  int32_t t, int32_t device, sknnr_index** out) {
+    if (!out) return fail(SKNNR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!ref || n_ref < 1 || d < 1) return fail(SKNNR_ERR_INVALID, "ref must be a non-empty (n_ref, d) matrix");
+    if (n_ref > 0x7fffff00L) return fail(SKNNR_ERR_UNSUPPORTED, "n_ref = %ld exceeds 2^31 - 256", (long)n_ref);
+    if (y && t < 1) return fail(SKNNR_ERR_INVALID, "t must be >= 1 when y is given");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)
+        return fail(SKNNR_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= n_dev) return fail(SKNNR_ERR_INVALID, "device %d out of range [0, %d)", device, n_dev);
+    HIP_TRY(hipSetDevice(device));
+
+    sknnr_index* ix = new (std::nothrow) sknnr_index();
+    if (!ix) return fail(SKNNR_ERR_INVALID, "out of host memory");
+    struct Guard {
+        sknnr_index* p;
+        ~Guard() { delete p; }
+    } guard{ix};
+    ix->device = device;
+    ix->n_ref = n_ref;
+    ix->d = d;
+    ix->t = y ? t : 0;
+
+    const size_t nd = (size_t)n_ref * d;
+    HIP_TRY(ix->ref64.ensure(nd));
+    HIP_TRY(hipMemcpy(ix->ref64.p, ref, nd * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ix->rn64.ensure(n_ref));
+    row_norms_kernel<<<dim3((unsigned)((n_ref + 255) / 256)), dim3(256)>>>(ix->ref64.p, n_ref, d, ix->rn64.p);
+    HIP_TRY(hipGetLastError());
+    if (y) {
+        HIP_TRY(ix->y64.ensure((size_t)n_ref * t));
+        HIP_TRY(hipMemcpy(ix->y64.p, y, (size_t)n_ref * t * sizeof(double), hipMemcpyHostToDevice));
+    }
+
+    // ---- coarse image: centred, power-of-two scaled, split into f16 hi/lo, fragment order
+    const int ks = (d + 15) / 16;
+    if (ks <= kMaxKs) {
+        ix->ks = ks;
+        const int dp = 16 * ks;
+        ix->mu.assign(dp, 0.0);
+        for (int c = 0; c < d; ++c) {
+            long double acc = 0;
+            for (int64_t i = 0; i < n_ref; ++i) acc += ref[i * d + c];
+            ix->mu[c] = (double)(acc / n_ref);
+        }
+        double amax = 0.0;
+        for (int64_t i = 0; i < n_ref; ++i)
+            for (int c = 0; c < d; ++c) amax = std::max(amax, std::fabs(ref[i * d + c] - ix->mu[c]));
+        if (!(amax < std::numeric_limits<double>::infinity()))
+            return fail(SKNNR_ERR_INVALID, "reference rows contain non-finite values");
+        // A = -2 s (r - mu) must stay <= 256 in magnitude: 2 s amax <= 256
+        int e = 0;
+        if (amax > 0.0) {
+            (void)std::frexp(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
+            e = 7 - e;                   // s * amax in [64, 128)
+        }
+        ix->s = std::ldexp(1.0, e);
+        const double s = ix->s;
+
+        const int tps = tiles_per_stage(ks);
+        const long n_tiles = ((n_ref + 31) / 32 + tps - 1) / tps * tps;
+        ix->n_stages = (int)(n_tiles / tps);
+        const size_t tb = tile_bytes(ks);
+        std::vector<char> img(n_tiles * tb);
+        double ymax2 = 0.0;
+        for (long tile = 0; tile < n_tiles; ++tile) {
+            char* rec = img.data() + tile * tb;
+            uint16_t* frag = reinterpret_cast<uint16_t*>(rec);
+            for (int part = 0; part < 2; ++part)
+                for (int step = 0; step < ks; ++step)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const long row = tile * 32 + (lane & 31);
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = step * 16 + 8 * (lane >> 5) + j;
+                            double a = 0.0;
+                            if (row < n_ref && k < d) a = -2.0 * s * (ref[row * d + k] - ix->mu[k]);
+                            const uint16_t hi = f64_to_f16_bits(a);
+                            uint16_t bits = hi;
+                            if (part == 1) bits = f64_to_f16_bits(a - f16_bits_to_f64(hi));
+                            frag[((size_t)(part * ks + step) * 64 + lane) * 8 + j] = bits;
+                        }
+                    }
+            float* ci = reinterpret_cast<float*>(rec + tile_frag_bytes(ks));
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const long row = tile * 32 + acc_row(r, h);
+                    float v = std::numeric_limits<float>::infinity();
+                    if (row < n_ref) {
+                        double yn = 0.0;
+                        for (int c = 0; c < d; ++c) {
+                            const double b = s * (ref[row * d + c] - ix->mu[c]);
+                            yn += b * b;
+                        }
+                        ymax2 = std::max(ymax2, yn);
+                        v = (float)yn;
+                    }
+                    ci[h * 16 + r] = v;
+                }
+        }
+        ix->ymax = std::sqrt(ymax2);
+        HIP_TRY(ix->rimg.ensure(img.size()));
+        HIP_TRY(hipMemcpy(ix->rimg.p, img.data(), img.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ix->mu_dev.ensure(dp));
+        HIP_TRY(hipMemcpy(ix->mu_dev.p, ix->mu.data(), dp * sizeof(double), hipMemcpyHostToDevice));
+    }
+
+    HIP_TRY(ix->fail_count.ensure(4));
+    HIP_TRY(ix->fail_total.ensure(2));
+    HIP_TRY(hipMemset(ix->fail_total.p, 0, 16));
+    HIP_TRY(hipEventCreate(&ix->ev_call0));
+    HIP_TRY(hipEventCreate(&ix->ev_call1));
+    HIP_TRY(hipDeviceSynchronize());
+    guard.p = nullptr;
+    *out = ix;
+    return SKNNR_OK;
+}
+
+extern "C" void sknnr_index_destroy(sknnr_index* ix) { delete ix; }
+
+extern "C" int sknnr_index_set_affine(sknnr_index* ix, int32_t d_in, const double* center,
+                                      const double* scale, const double* proj) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    if (d_in < 1) return fail(SKNNR_ERR_INVALID, "d_in must be >= 1");
+    if (!proj && d_in != ix->d)
+        return fail(SKNNR_ERR_INVALID, "without a projection d_in (%d) must equal d (%d)", d_in, ix->d);
+    HIP_TRY(hipSetDevice(ix->device));
+    ix->d_in = d_in;
+    ix->has_center = center != nullptr;
+    ix->has_scale = scale != nullptr;
+    ix->has_proj = proj != nullptr;
+    if (center) {
+        HIP_TRY(ix->center.ensure(d_in));
+        HIP_TRY(hipMemcpy(ix->center.p, center, d_in * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (scale) {
+        HIP_TRY(ix->scale.ensure(d_in));
+        HIP_TRY(hipMemcpy(ix->scale.p, scale, d_in * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (proj) {
+        const int dp = ix->ks > 0 ? 16 * ix->ks : ((ix->d + 15) / 16) * 16;
+        std::vector<double> padded((size_t)d_in * dp, 0.0);
+        for (int c = 0; c < d_in; ++c)
+            for (int j = 0; j < ix->d; ++j) padded[(size_t)c * dp + j] = proj[(size_t)c * ix->d + j];
+        HIP_TRY(ix->proj.ensure(padded.size()));
+        HIP_TRY(hipMemcpy(ix->proj.p, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    ix->has_affine = true;
+    return SKNNR_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// stats
+// ----------------------------------------------------------------------------------------
+static void resolve_timing(sknnr_index* ix) {
+    if (!ix->timing_pending) return;
+    ix->timing_pending = false;
+    if (hipEventSynchronize(ix->ev_call1) != hipSuccess) return;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ix->ev_call0, ix->ev_call1) == hipSuccess) ix->stats.last_kernel_ms = ms;
+    double cms = 0.0;
+    for (size_t i = 0; i < ix->coarse_events_used; ++i) {
+        float m = 0.f;
+        if (hipEventElapsedTime(&m, ix->coarse_events[i].first, ix->coarse_events[i].second) == hipSuccess) cms += m;
+    }
+    ix->stats.last_coarse_ms = cms;
+}
+
+extern "C" int sknnr_get_stats(const sknnr_index* cix, sknnr_stats* out) {
+    if (!cix || !out) return fail(SKNNR_ERR_INVALID, "NULL argument");
+    sknnr_index* ix = const_cast<sknnr_index*>(cix);
+    (void)hipSetDevice(ix->device);
+    resolve_timing(ix);
+    long long total = 0;
+    if (hipMemcpy(&total, ix->fail_total.p, sizeof total, hipMemcpyDeviceToHost) == hipSuccess)
+        ix->stats.exact_fallbacks = total;
+    *out = ix->stats;
+    return SKNNR_OK;
+}
+
+extern "C" int sknnr_reset_stats(sknnr_index* ix) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(ix->fail_total.p, 0, 16);
+    ix->stats = sknnr_stats{};
+    return SKNNR_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// launch helpers
+// ----------------------------------------------------------------------------------------
+namespace {
+
+__global__ void add_counter_kernel(const int* __restrict__ cnt, long long* __restrict__ total) { *total += *cnt; }
+
+int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool affine, double* xt,
+                hipStream_t st) {
+    PrepArgs a{};
+    a.x = x;
+    a.nq = nq;
+    a.nq_pad = nq_pad;
+    a.d_in = affine ? ix->d_in : ix->d;
+    a.d = ix->d;
+    a.ks = ix->ks;
+    a.center = (affine && ix->has_center) ? ix->center.p : nullptr;
+    a.scale = (affine && ix->has_scale) ? ix->scale.p : nullptr;
+    a.proj = (affine && ix->has_proj) ? ix->proj.p : nullptr;
+    a.mu = ix->mu_dev.p;
+    a.s = ix->s;
+    a.xt = xt;
+    a.qimg = ix->qimg.p;
+    a.qnc = ix->qnc.p;
+    const int ldx = a.d_in | 1;
+    const size_t lim = 150 * 1024;
+    if ((size_t)256 * ldx * 8 <= lim) {
+        const size_t sh = (size_t)256 * ldx * 8;
+        HIP_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        prep_queries_kernel<256><<<dim3((unsigned)(nq_pad / 256)), dim3(256), sh, st>>>(a);
+    } else if ((size_t)128 * ldx * 8 <= lim) {
+        const size_t sh = (size_t)128 * ldx * 8;
+        HIP_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        prep_queries_kernel<128><<<dim3((unsigned)(nq_pad / 128)), dim3(128), sh, st>>>(a);
+    } else if ((size_t)64 * ldx * 8 <= lim) {
+        const size_t sh = (size_t)64 * ldx * 8;
+        HIP_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        prep_queries_kernel<64><<<dim3((unsigned)(nq_pad / 64)), dim3(64), sh, st>>>(a);
+    } else {
+        return fail(SKNNR_ERR_UNSUPPORTED, "d_in = %d is too wide for the query preparation kernel (max 299)", a.d_in);
+    }
+    HIP_TRY(hipGetLastError());
+    return SKNNR_OK;
+}
+
+template <int KS>
+int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
+    constexpr int NQB = (KS <= 4) ? 2 : 1;
+    constexpr int QPB = kCoarseWaves * NQB * 32;
+    constexpr int TPS = tiles_per_stage(KS);
+    constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS);
+    auto kern = coarse_kernel<KS, kListLen, NQB>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(kCoarseThreads), sh, st>>>(
+        ix->rimg.p, ix->n_stages, ix->qimg.p, ix->cand_val.p, ix->cand_idx.p);
+    HIP_TRY(hipGetLastError());
+    return SKNNR_OK;
+}
+
+int launch_coarse(sknnr_index* ix, long nq_pad, hipStream_t st) {
+    switch (ix->ks) {
+        case 1: return launch_coarse_ks<1>(ix, nq_pad, st);
+        case 2: return launch_coarse_ks<2>(ix, nq_pad, st);
+        case 3: return launch_coarse_ks<3>(ix, nq_pad, st);
+        case 4: return launch_coarse_ks<4>(ix, nq_pad, st);
+        case 5: return launch_coarse_ks<5>(ix, nq_pad, st);
+        case 6: return launch_coarse_ks<6>(ix, nq_pad, st);
+        case 7: return launch_coarse_ks<7>(ix, nq_pad, st);
+        case 8: return launch_coarse_ks<8>(ix, nq_pad, st);
+    }
+    return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for ks = %d", ix->ks);
+}
+
+size_t scan_lds_bytes(int d, int kk, int threads) {
+    size_t b = 8 * (size_t)((d + 1) & ~1);
+    b += 12 * (size_t)kk * threads + 4 * (((size_t)kk * threads) & 1);
+    b += 8 * (size_t)kk + 4 * (size_t)(kk + (kk & 1));
+    b += 32 + 16 + 16 + 16;
+    return b;
+}
+
+int launch_scan(const SelectArgs& s, const int* list, const int* count, long max_items, hipStream_t st) {
+    int threads = s.kk <= 32 ? 256 : (s.kk <= 64 ? 128 : 64);
+    size_t sh = scan_lds_bytes(s.d, s.kk, threads);
+    while (sh > 150 * 1024 && threads > 64) {
+        threads >>= 1;
+        sh = scan_lds_bytes(s.d, s.kk, threads);
+    }
+    if (sh > 150 * 1024)
+        return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", s.k, s.d);
+    ScanArgs a{s, list, count};
+    HIP_TRY(hipFuncSetAttribute((const void*)exact_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    const long blocks = std::max<long>(1, std::min<long>(max_items, 256L * 8));
+    exact_scan_kernel<<<dim3((unsigned)blocks), dim3(threads), sh, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return SKNNR_OK;
+}
+
+struct CallCtx {
+    sknnr_index* ix;
+    const sknnr_query_opts* o;
+    int kk;
+    bool coarse;
+};
+
+int validate_call(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o, int64_t* out_idx) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    if (!o) return fail(SKNNR_ERR_INVALID, "opts is NULL");
+    if (nq < 0) return fail(SKNNR_ERR_INVALID, "nq must be >= 0");
+    if (!out_idx && nq > 0) return fail(SKNNR_ERR_INVALID, "out_idx is NULL");
+    if (o->n_neighbors <= 0) return fail(SKNNR_ERR_INVALID, "Expected n_neighbors > 0. Got %d", o->n_neighbors);
+    if (!q && !o->exclude_self) return fail(SKNNR_ERR_INVALID, "q is NULL but exclude_self is not set");
+    const long n_fit = ix->n_ref;
+    if (o->exclude_self) {
+        if (o->n_neighbors + 1 > n_fit)
+            return fail(SKNNR_ERR_K_TOO_LARGE,
+                        "Expected n_neighbors < n_samples_fit, but n_neighbors = %d, n_samples_fit = %ld, n_samples = %ld",
+                        o->n_neighbors, n_fit, (long)nq);
+        if (!q && (o->row_offset < 0 || o->row_offset + nq > n_fit))
+            return fail(SKNNR_ERR_INVALID, "self query rows [%ld, %ld) outside the %ld reference rows",
+                        (long)o->row_offset, (long)(o->row_offset + nq), n_fit);
+    } else if (o->n_neighbors > n_fit) {
+        return fail(SKNNR_ERR_K_TOO_LARGE,
+                    "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %ld, n_samples = %ld",
+                    o->n_neighbors, n_fit, (long)nq);
+    }
+    if (o->apply_affine && !ix->has_affine)
+        return fail(SKNNR_ERR_INVALID, "apply_affine is set but no affine map was installed");
+    if (o->formula != SKNNR_FORMULA_EXPANDED && o->formula != SKNNR_FORMULA_DIRECT)
+        return fail(SKNNR_ERR_INVALID, "unknown formula %d", o->formula);
+    if (o->n_neighbors + (o->exclude_self ? 1 : 0) > kScanMaxKK)
+        return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d exceeds the HIP backend's limit of %d", o->n_neighbors,
+                    kScanMaxKK - 1);
+    if (std::abs(o->decimals) > 300) return fail(SKNNR_ERR_INVALID, "decimals out of range");
+    return SKNNR_OK;
+}
+
+// Device-resident core: nq rows at xdev (raw if affine else transformed), outputs on device.
+int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_opts* o, double* d_dist,
+               long* d_idx, hipStream_t st) {
+    const int kk = o->n_neighbors + (o->exclude_self ? 1 : 0);
+    const bool affine = o->apply_affine != 0 && xdev != nullptr;
+    const bool self_rows = xdev == nullptr;
+    const bool coarse = ix->ks > 0 && kk <= kCoarseMaxKK;
+    const int d_x = affine ? ix->d_in : ix->d;
+
+    ix->coarse_events_used = 0;
+    HIP_TRY(hipEventRecord(ix->ev_call0, st));
+    for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
+        const long n = std::min(kChunkRows, nq - c0);
+        const long n_pad = (n + 511) / 512 * 512;
+        const double* xin = self_rows ? ix->ref64.p + (o->row_offset + c0) * ix->d : xdev + c0 * d_x;
+        const double* xq = xin;  // transformed rows the exact stages read
+        if (affine) {
+            HIP_TRY(ix->xt.ensure((size_t)std::min(kChunkRows, nq) * ix->d));
+            xq = ix->xt.p;
+        }
+
+        SelectArgs s{};
+        s.xq = xq;
+        s.ref = ix->ref64.p;
+        s.rn = ix->rn64.p;
+        s.nq = n;
+        s.d = ix->d;
+        s.n_ref = (int)ix->n_ref;
+        s.k = o->n_neighbors;
+        s.kk = kk;
+        s.exclude_self = o->exclude_self ? 1 : 0;
+        s.deterministic = o->deterministic ? 1 : 0;
+        s.formula = o->formula;
+        s.pow10_is_divisor = o->decimals < 0;
+        s.pow10 = std::pow(10.0, std::abs(o->decimals));
+        s.row_offset = o->row_offset + c0;
+        s.out_dist = d_dist ? d_dist + c0 * o->n_neighbors : nullptr;
+        s.out_idx = d_idx + c0 * o->n_neighbors;
+
+        if (coarse) {
+            const long cap_pad = (std::min(kChunkRows, nq) + 511) / 512 * 512;
+            HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
+            HIP_TRY(ix->qnc.ensure(cap_pad));
+            HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * kListLen));
+            HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * kListLen));
+            HIP_TRY(ix->fail_list.ensure(cap_pad));
+            HIP_TRY(hipMemsetAsync(ix->fail_count.p, 0, 16, st));
+            int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p : nullptr, st);
+            if (rc) return rc;
+
+            if (ix->coarse_events_used == ix->coarse_events.size()) {
+                hipEvent_t e0, e1;
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventCreate(&e1));
+                ix->coarse_events.emplace_back(e0, e1);
+            }
+            auto& ev = ix->coarse_events[ix->coarse_events_used++];
+            HIP_TRY(hipEventRecord(ev.first, st));
+            rc = launch_coarse(ix, n_pad, st);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev.second, st));
+
+            FinalizeArgs f{};
+            f.s = s;
+            f.cand_val = ix->cand_val.p;
+            f.cand_idx = ix->cand_idx.p;
+            f.qnc = ix->qnc.p;
+            f.inv_s2 = 1.0 / (ix->s * ix->s);
+            f.eps_c = eps_units(ix->ks) * std::ldexp(1.0, -24);
+            f.ymax = ix->ymax;
+            f.fail_list = ix->fail_list.p;
+            f.fail_count = ix->fail_count.p;
+            const long threads = n * 2 * kListLen;
+            finalize_kernel<kListLen><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(f);
+            HIP_TRY(hipGetLastError());
+            rc = launch_scan(s, ix->fail_list.p, ix->fail_count.p, n, st);
+            if (rc) return rc;
+            // keep a running total on the device; sknnr_get_stats reads it (no sync here)
+            add_counter_kernel<<<dim3(1), dim3(1), 0, st>>>(ix->fail_count.p, ix->fail_total.p);
+            HIP_TRY(hipGetLastError());
+            ix->stats.coarse_queries += n;
+        } else {
+            if (affine) {
+                // transform only: reuse the prep kernel when the coarse image exists, else fail loudly
+                if (ix->ks == 0)
+                    return fail(SKNNR_ERR_UNSUPPORTED, "d = %d > 128 with an affine map is outside the HIP envelope", ix->d);
+                const long cap_pad = (std::min(kChunkRows, nq) + 511) / 512 * 512;
+                HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
+                HIP_TRY(ix->qnc.ensure(cap_pad));
+                int rc = launch_prep(ix, xin, n, n_pad, true, ix->xt.p, st);
+                if (rc) return rc;
+            }
+            int rc = launch_scan(s, nullptr, nullptr, n, st);
+            if (rc) return rc;
+            ix->stats.exact_only_queries += n;
+        }
+    }
+    HIP_TRY(hipEventRecord(ix->ev_call1, st));
+    ix->timing_pending = true;
+    ix->stats.queries += nq;
+    return SKNNR_OK;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
+// kneighbors
+// ----------------------------------------------------------------------------------------
+extern "C" int sknnr_kneighbors(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o,
+                                double* out_dist, int64_t* out_idx, int32_t mem, void* stream) {
+    int rc = validate_call(ix, q, nq, o, out_idx);
+    if (rc) return rc;
+    if (nq == 0) return SKNNR_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    const int k = o->n_neighbors;
+    if (mem == SKNNR_MEM_DEVICE) {
+        return run_device(ix, q, nq, o, out_dist, (long*)out_idx, (hipStream_t)stream);
+    }
+    if (mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    // host buffers: stage chunk by chunk through device buffers on the default stream
+    hipStream_t st = nullptr;
+    const int d_x = (o->apply_affine && q) ? ix->d_in : ix->d;
+    for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
+        const long n = std::min<long>(kChunkRows, nq - c0);
+        const double* xdev = nullptr;
+        if (q) {
+            HIP_TRY(ix->xstage.ensure((size_t)n * d_x));
+            HIP_TRY(hipMemcpyAsync(ix->xstage.p, q + c0 * d_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, st));
+            xdev = ix->xstage.p;
+        }
+        HIP_TRY(ix->dist_stage.ensure((size_t)n * k));
+        HIP_TRY(ix->idx_stage.ensure((size_t)n * k));
+        sknnr_query_opts oc = *o;
+        oc.row_offset = o->row_offset + c0;
+        rc = run_device(ix, xdev, n, &oc, ix->dist_stage.p, ix->idx_stage.p, st);
+        if (rc) return rc;
+        if (out_dist)
+            HIP_TRY(hipMemcpyAsync(out_dist + c0 * k, ix->dist_stage.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_idx + c0 * k, ix->idx_stage.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SKNNR_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// predict
+// ----------------------------------------------------------------------------------------
+static int launch_predict(sknnr_index* ix, const double* dist, const long* idx, const double* w, long nq, int k,
+                          int mode, double* out, hipStream_t st) {
+    PredictArgs a{};
+    a.y = ix->y64.p;
+    a.dist = dist;
+    a.idx = idx;
+    a.w = w;
+    a.nq = nq;
+    a.k = k;
+    a.t = ix->t;
+    a.mode = mode;
+    a.out = out;
+    const long total = nq * ix->t;
+    predict_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return SKNNR_OK;
+}
+
+extern "C" int sknnr_predict_from_neighbors(sknnr_index* ix, const double* dist, const int64_t* idx, const double* w,
+                                            int64_t nq, int32_t k, int32_t mode, double* out_pred, int32_t mem,
+                                            void* stream) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    if (ix->t < 1) return fail(SKNNR_ERR_NO_TARGETS, "the index was created without targets");
+    if (nq < 0 || k < 1 || !idx || !out_pred) return fail(SKNNR_ERR_INVALID, "bad argument");
+    if (mode == SKNNR_WEIGHTS_DISTANCE && !dist) return fail(SKNNR_ERR_INVALID, "distance weights need dist");
+    if (mode == SKNNR_WEIGHTS_EXPLICIT && !w) return fail(SKNNR_ERR_INVALID, "explicit weights need w");
+    if (mode < 0 || mode > 2) return fail(SKNNR_ERR_INVALID, "unknown weight mode %d", mode);
+    if (nq == 0) return SKNNR_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    if (mem == SKNNR_MEM_DEVICE)
+        return launch_predict(ix, dist, (const long*)idx, w, nq, k, mode, out_pred, (hipStream_t)stream);
+    hipStream_t st = nullptr;
+    DevBuf<double> dd, dw, dout;
+    DevBuf<long> di;
+    int rc = SKNNR_OK;
+    do {
+        hipError_t e;
+        if ((e = di.ensure((size_t)nq * k)) != hipSuccess || (e = dout.ensure((size_t)nq * ix->t)) != hipSuccess) {
+            rc = fail(SKNNR_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+            break;
+        }
+        (void)hipMemcpy(di.p, idx, (size_t)nq * k * sizeof(long), hipMemcpyHostToDevice);
+        if (dist) {
+            if ((e = dd.ensure((size_t)nq * k)) != hipSuccess) { rc = fail(SKNNR_ERR_HIP, "hipMalloc failed"); break; }
+            (void)hipMemcpy(dd.p, dist, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice);
+        }
+        if (w) {
+            if ((e = dw.ensure((size_t)nq * k)) != hipSuccess) { rc = fail(SKNNR_ERR_HIP, "hipMalloc failed"); break; }
+            (void)hipMemcpy(dw.p, w, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice);
+        }
+        rc = launch_predict(ix, dist ? dd.p : nullptr, di.p, w ? dw.p : nullptr, nq, k, mode, dout.p, st);
+        if (rc) break;
+        e = hipMemcpy(out_pred, dout.p, (size_t)nq * ix->t * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(SKNNR_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
+    } while (0);
+    dd.release();
+    dw.release();
+    dout.release();
+    di.release();
+    return rc;
+}
+
+extern "C" int sknnr_predict(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o, double* out_pred,
+                             double* out_dist, int64_t* out_idx, int32_t mem, void* stream) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    if (ix->t < 1) return fail(SKNNR_ERR_NO_TARGETS, "the index was created without targets");
+    if (!o) return fail(SKNNR_ERR_INVALID, "opts is NULL");
+    if (!out_pred && nq > 0) return fail(SKNNR_ERR_INVALID, "out_pred is NULL");
+    if (o->weight_mode == SKNNR_WEIGHTS_EXPLICIT)
+        return fail(SKNNR_ERR_INVALID, "explicit weights go through sknnr_predict_from_neighbors");
+    if (o->weight_mode != SKNNR_WEIGHTS_UNIFORM && o->weight_mode != SKNNR_WEIGHTS_DISTANCE)
+        return fail(SKNNR_ERR_INVALID, "unknown weight mode %d", o->weight_mode);
+    static int64_t dummy_idx;
+    int rc = validate_call(ix, q, nq, o, out_idx ? out_idx : &dummy_idx);
+    if (rc) return rc;
+    if (nq == 0) return SKNNR_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    const int k = o->n_neighbors;
+
+    if (mem == SKNNR_MEM_DEVICE) {
+        hipStream_t st = (hipStream_t)stream;
+        double* dd = out_dist;
+        long* di = (long*)out_idx;
+        if (!dd) {
+            HIP_TRY(ix->dist_stage.ensure((size_t)nq * k));
+            dd = ix->dist_stage.p;
+        }
+        if (!di) {
+            HIP_TRY(ix->idx_stage.ensure((size_t)nq * k));
+            di = ix->idx_stage.p;
+        }
+        rc = run_device(ix, q, nq, o, dd, di, st);
+        if (rc) return rc;
+        return launch_predict(ix, dd, di, nullptr, nq, k, o->weight_mode, out_pred, st);
+    }
+    if (mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    hipStream_t st = nullptr;
+    const int d_x = (o->apply_affine && q) ? ix->d_in : ix->d;
+    for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
+        const long n = std::min<long>(kChunkRows, nq - c0);
+        const double* xdev = nullptr;
+        if (q) {
+            HIP_TRY(ix->xstage.ensure((size_t)n * d_x));
+            HIP_TRY(hipMemcpyAsync(ix->xstage.p, q + c0 * d_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, st));
+            xdev = ix->xstage.p;
+        }
+        HIP_TRY(ix->dist_stage.ensure((size_t)n * k));
+        HIP_TRY(ix->idx_stage.ensure((size_t)n * k));
+        HIP_TRY(ix->pred_stage.ensure((size_t)n * ix->t));
+        sknnr_query_opts oc = *o;
+        oc.row_offset = o->row_offset + c0;
+        rc = run_device(ix, xdev, n, &oc, ix->dist_stage.p, ix->idx_stage.p, st);
+        if (rc) return rc;
+        rc = launch_predict(ix, ix->dist_stage.p, ix->idx_stage.p, nullptr, n, k, o->weight_mode, ix->pred_stage.p, st);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out_pred + c0 * ix->t, ix->pred_stage.p, (size_t)n * ix->t * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (out_dist)
+            HIP_TRY(hipMemcpyAsync(out_dist + c0 * k, ix->dist_stage.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (out_idx)
+            HIP_TRY(hipMemcpyAsync(out_idx + c0 * k, ix->idx_stage.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SKNNR_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// crosswalk
+// ----------------------------------------------------------------------------------------
+extern "C" int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int64_t* idx, int64_t n, int64_t* out,
+                               int32_t device, int32_t mem, void* stream) {
+    if (!table || !idx || !out || n < 0 || n_table < 1) return fail(SKNNR_ERR_INVALID, "bad argument");
+    if (n == 0) return SKNNR_OK;
+    HIP_TRY(hipSetDevice(device));
+    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 256L * 16);
+    if (mem == SKNNR_MEM_DEVICE) {
+        crosswalk_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>((const long*)table, (const long*)idx, n, (long*)out);
+        HIP_TRY(hipGetLastError());
+        return SKNNR_OK;
+    }
+    DevBuf<long> dt, di, dout;
+    HIP_TRY(dt.ensure(n_table));
+    HIP_TRY(di.ensure(n));
+    HIP_TRY(dout.ensure(n));
+    (void)hipMemcpy(dt.p, table, n_table * sizeof(long), hipMemcpyHostToDevice);
+    (void)hipMemcpy(di.p, idx, n * sizeof(long), hipMemcpyHostToDevice);
+    crosswalk_kernel<<<dim3(blocks), dim3(256)>>>(dt.p, di.p, n, dout.p);
+    hipError_t e = hipMemcpy(out, dout.p, n * sizeof(long), hipMemcpyDeviceToHost);
+    dt.release();
+    di.release();
+    dout.release();
+    if (e != hipSuccess) return fail(SKNNR_ERR_HIP, "crosswalk failed: %s", hipGetErrorString(e));
+    return SKNNR_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// diagnostics
+// ----------------------------------------------------------------------------------------
+template <int KS>
+static void launch_matrix(sknnr_index* ix, long n_tiles, long nqb, long nq, float* out) {
+    coarse_matrix_kernel<KS><<<dim3((unsigned)n_tiles, (unsigned)nqb), dim3(64)>>>(ix->rimg.p, ix->qimg.p, (int)ix->n_ref, (int)nq, out);
+}
+
+extern "C" int sknnr_debug_coarse_matrix(sknnr_index* ix, const double* q, int64_t nq, float* out, double* out_qnorm,
+                                         double* out_scale, double* out_eps) {
+    if (!ix || !q || !out || nq < 1) return fail(SKNNR_ERR_INVALID, "bad argument");
+    if (ix->ks == 0) return fail(SKNNR_ERR_UNSUPPORTED, "no coarse image (d > 128)");
+    if ((double)nq * (double)ix->n_ref > 16777216.0) return fail(SKNNR_ERR_INVALID, "nq * n_ref must be <= 2^24");
+    HIP_TRY(hipSetDevice(ix->device));
+    const long n_pad = (nq + 511) / 512 * 512;
+    HIP_TRY(ix->xstage.ensure((size_t)nq * ix->d));
+    HIP_TRY(hipMemcpy(ix->xstage.p, q, (size_t)nq * ix->d * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ix->qimg.ensure((size_t)(n_pad / 32) * 2 * ix->ks * 64));
+    HIP_TRY(ix->qnc.ensure(n_pad));
+    int rc = launch_prep(ix, ix->xstage.p, nq, n_pad, false, nullptr, nullptr);
+    if (rc) return rc;
+    DevBuf<float> dout;
+    HIP_TRY(dout.ensure((size_t)nq * ix->n_ref));
+    const long n_tiles = (ix->n_ref + 31) / 32, nqb = (nq + 31) / 32;
+    switch (ix->ks) {
+        case 1: launch_matrix<1>(ix, n_tiles, nqb, nq, dout.p); break;
+        case 2: launch_matrix<2>(ix, n_tiles, nqb, nq, dout.p); break;
+        case 3: launch_matrix<3>(ix, n_tiles, nqb, nq, dout.p); break;
+        case 4: launch_matrix<4>(ix, n_tiles, nqb, nq, dout.p); break;
+        case 5: launch_matrix<5>(ix, n_tiles, nqb, nq, dout.p); break;
+        case 6: launch_matrix<6>(ix, n_tiles, nqb, nq, dout.p); break;
+        case 7: launch_matrix<7>(ix, n_tiles, nqb, nq, dout.p); break;
+        case 8: launch_matrix<8>(ix, n_tiles, nqb, nq, dout.p); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)nq * ix->n_ref * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_qnorm) e = hipMemcpy(out_qnorm, ix->qnc.p, nq * sizeof(double), hipMemcpyDeviceToHost);
+    dout.release();
+    if (e != hipSuccess) return fail(SKNNR_ERR_HIP, "debug matrix failed: %s", hipGetErrorString(e));
+    if (out_scale) *out_scale = ix->s;
+    if (out_eps) *out_eps = eps_units(ix->ks) * std::ldexp(1.0, -24);
+    return SKNNR_OK;
+}
