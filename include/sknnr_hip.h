@@ -128,6 +128,16 @@ void sknnr_index_destroy(sknnr_index* index);
 int sknnr_index_set_affine(sknnr_index* index, int32_t d_in, const double* center,
                            const double* scale, const double* proj);
 
+/*
+ * The same affine map as a stand-alone call (no handle): out = ((x - center) / scale) @ proj.
+ * Replaces X_transformed = self.transformer_.transform(X) at fit time (REF _base.py:251), so
+ * that the stored reference rows and later query rows go through one and the same float64
+ * fma chain.  x, out: host, (n, d_in) and (n, d); center/scale/proj as in set_affine.
+ */
+int sknnr_affine_transform(const double* x, int64_t n, int32_t d_in, const double* center,
+                           const double* scale, const double* proj, int32_t d, double* out,
+                           int32_t device);
+
 /* Read back sizes: any pointer may be NULL. */
 int sknnr_index_shape(const sknnr_index* index, int64_t* n_ref, int32_t* d, int32_t* t,
                       int32_t* d_in, int32_t* device);

@@ -1,0 +1,25 @@
+"""sknnr_amd -- MI355X-native backend for sknnr's kneighbors()/predict() hot path.
+
+Same estimator surface as lemma-osu/sknnr's Euclidean family; the arithmetic runs in
+hand-written HIP kernels for gfx950 behind the C ABI of ``include/sknnr_hip.h``.
+Importing the package is cheap and works without a GPU; fitting or querying an
+estimator needs the built library and an MI355X (there is no CPU fallback).
+"""
+
+from ._base import RawKNNRegressor
+from ._estimators import (
+    EuclideanKNNRegressor,
+    GNNRegressor,
+    MahalanobisKNNRegressor,
+    MSNRegressor,
+)
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "RawKNNRegressor",
+    "EuclideanKNNRegressor",
+    "MahalanobisKNNRegressor",
+    "MSNRegressor",
+    "GNNRegressor",
+]

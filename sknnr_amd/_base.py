@@ -1,0 +1,398 @@
+"""Estimator surface of the MI355X backend: the reference's L3 layer re-stated over
+:class:`sknnr_amd._engine.KNNEngine`.
+
+Mirrors /root/reference/src/sknnr/_base.py -- same class names, constructor parameters,
+method signatures, fitted attributes and error messages -- but no arithmetic of the
+hot path happens in Python or scikit-learn: ``kneighbors`` / ``predict`` / the fit-time
+independent prediction are launches of ``libsknnr_hip.so``.  There is no CPU fallback;
+metrics other than Euclidean raise.
+
+    RawKNNRegressor                  REF _base.py:43-182
+    TransformedKNeighborsRegressor   REF _base.py:185-358
+    YFitMixin                        REF _base.py:361-374
+    OrdinationKNeighborsRegressor    REF _base.py:377-408
+"""
+
+from __future__ import annotations
+
+import numbers
+from abc import ABC, abstractmethod
+
+import numpy as np
+from sklearn.base import BaseEstimator, MultiOutputMixin, RegressorMixin
+from sklearn.exceptions import NotFittedError
+from sklearn.metrics import r2_score
+from sklearn.utils.validation import _is_arraylike, check_is_fitted, validate_data
+
+from . import _native
+from ._engine import KNNEngine, default_device, is_torch_cuda_tensor
+
+_EUCLIDEAN_NAMES = {"euclidean", "l2"}
+_ALGORITHMS = {"auto", "brute", "kd_tree", "ball_tree"}
+
+
+def _effective_metric(metric, p, metric_params):
+    """Only the Euclidean metric exists on the device (SKL/neighbors/_base.py:429-472 maps
+    minkowski/p=2 to 'euclidean')."""
+    if metric_params:
+        raise NotImplementedError(
+            "metric_params are not supported by the MI355X backend (Euclidean metric only)")
+    if callable(metric):
+        raise NotImplementedError(
+            "callable metrics are not supported by the MI355X backend (Euclidean metric only)")
+    if metric == "minkowski":
+        if p != 2:
+            raise NotImplementedError(
+                f"minkowski with p={p} is not supported by the MI355X backend (p must be 2)")
+        return "euclidean"
+    if metric in _EUCLIDEAN_NAMES:
+        return "euclidean"
+    raise NotImplementedError(
+        f"metric={metric!r} is not supported by the MI355X backend (Euclidean metric only)")
+
+
+def _resolve_fit_method(algorithm, n_ref, d, k):
+    """Which of the reference's engines -- hence which float64 distance expression -- the
+    ``algorithm`` setting selects (SKL/neighbors/_base.py:620-648)."""
+    if algorithm not in _ALGORITHMS:
+        raise ValueError(f"unrecognized algorithm: {algorithm!r}")
+    if algorithm != "auto":
+        return algorithm
+    if d > 15 or (k is not None and k >= n_ref // 2):
+        return "brute"
+    return "kd_tree"
+
+
+class DFIndexCrosswalkMixin:
+    """Capture of a dataframe's index at fit time (REF _base.py:23-30)."""
+
+    def _set_dataframe_index_in(self, X) -> None:
+        index = getattr(X, "index", None)
+        if _is_arraylike(index):
+            self.dataframe_index_in_ = np.asarray(index)
+
+
+class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, BaseEstimator):
+    """k-nearest-neighbour regressor on the features as given, with sknnr's extras:
+    dataframe-index crosswalk, fit-time independent prediction/score and deterministic
+    neighbour ordering -- computed on the GPU.
+
+    Same parameters as ``sklearn.neighbors.KNeighborsRegressor`` (REF _base.py:53-73);
+    ``leaf_size`` and ``n_jobs`` are accepted and ignored (there is no tree and no thread
+    pool), ``algorithm`` only selects which of the reference's two float64 distance
+    expressions is reproduced.
+    """
+
+    DISTANCE_PRECISION_DECIMALS = 10
+
+    def __init__(self, n_neighbors=5, *, weights="uniform", algorithm="auto", leaf_size=30, p=2,
+                 metric="minkowski", metric_params=None, n_jobs=None):
+        self.n_neighbors = n_neighbors
+        self.weights = weights
+        self.algorithm = algorithm
+        self.leaf_size = leaf_size
+        self.p = p
+        self.metric = metric
+        self.metric_params = metric_params
+        self.n_jobs = n_jobs
+
+    # -- fitting -------------------------------------------------------------------------
+    def _check_params(self):
+        if not isinstance(self.n_neighbors, numbers.Integral) or isinstance(self.n_neighbors, bool):
+            raise TypeError(
+                f"n_neighbors does not take {type(self.n_neighbors)} value, enter integer value")
+        if self.n_neighbors <= 0:
+            raise ValueError(f"Expected n_neighbors > 0. Got {self.n_neighbors}")
+        if not (self.weights in (None, "uniform", "distance") or callable(self.weights)):
+            raise ValueError(
+                "weights not recognized: should be 'uniform', 'distance', or a callable function")
+        self.effective_metric_ = _effective_metric(self.metric, self.p, self.metric_params)
+        self.effective_metric_params_ = {}
+
+    def fit(self, X, y):
+        """Store the reference rows and targets in HBM and compute the independent
+        (leave-self-out) prediction and score (REF _base.py:104-109)."""
+        self._set_dataframe_index_in(X)
+        return self._fit_arrays(X, y, affine=None)
+
+    def _fit_arrays(self, X, y, affine, device=None):
+        self._check_params()
+        X, y = validate_data(self, X, y, multi_output=True, order="C", dtype=np.float64,
+                             ensure_all_finite=True, reset=True)
+        self._y = y
+        self._fit_X = X
+        self.n_samples_fit_ = X.shape[0]
+        self._fit_method = _resolve_fit_method(self.algorithm, X.shape[0], X.shape[1], self.n_neighbors)
+        self._affine = affine
+        self._device = default_device() if device is None else device
+        self._build_engine()
+        self._set_independent_prediction_attributes(y)
+        return self
+
+    def _build_engine(self):
+        y2 = self._y.reshape(-1, 1) if self._y.ndim == 1 else self._y
+        self._engine = KNNEngine(self._fit_X, np.asarray(y2, dtype=np.float64), device=self._device)
+        if self._affine is not None:
+            d_in, center, scale, proj = self._affine
+            self._engine.set_affine(d_in, center, scale, proj)
+
+    @property
+    def engine_(self) -> KNNEngine:
+        """The device engine; rebuilt lazily after unpickling."""
+        check_is_fitted(self, "_fit_X")
+        if getattr(self, "_engine", None) is None:
+            self._build_engine()
+        return self._engine
+
+    def __getstate__(self):
+        state = dict(super().__getstate__())
+        state["_engine"] = None  # device handles do not pickle; see engine_
+        return state
+
+    def _formula(self) -> str:
+        return "direct" if self._fit_method == "kd_tree" else "expanded"
+
+    def _set_independent_prediction_attributes(self, y) -> None:
+        """REF _base.py:37-40: predict and score with X=None."""
+        self.independent_prediction_ = self.predict(None)
+        self.independent_score_ = float(r2_score(y, self.independent_prediction_))
+
+    # -- queries -------------------------------------------------------------------------
+    def _validate_query(self, X):
+        if is_torch_cuda_tensor(X):
+            if X.ndim != 2 or X.shape[1] != self.n_features_in_:
+                raise ValueError(
+                    f"X has {X.shape[1] if X.ndim == 2 else '?'} features, but {type(self).__name__} "
+                    f"is expecting {self.n_features_in_} features as input.")
+            return X
+        return validate_data(self, X, reset=False, order="C", dtype=np.float64, ensure_all_finite=True)
+
+    def _resolve_k(self, n_neighbors):
+        if n_neighbors is None:
+            return self.n_neighbors
+        if not isinstance(n_neighbors, numbers.Integral) or isinstance(n_neighbors, bool):
+            raise TypeError(
+                "n_neighbors does not take %s value, enter integer value" % type(n_neighbors))
+        if n_neighbors <= 0:
+            raise ValueError("Expected n_neighbors > 0. Got %d" % n_neighbors)
+        return int(n_neighbors)
+
+    def _kneighbors_engine(self, X, k, *, apply_affine, use_deterministic_ordering, row_offset=0,
+                           n_self_rows=None, return_distance=True):
+        try:
+            return self.engine_.kneighbors(
+                X, k, exclude_self=X is None, deterministic=use_deterministic_ordering,
+                decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
+                apply_affine=apply_affine, row_offset=row_offset, n_self_rows=n_self_rows,
+                return_distance=return_distance)
+        except _native.HipBackendError as err:
+            if err.code == _native.ERR_K_TOO_LARGE:
+                raise ValueError(err.message) from None
+            raise
+
+    def kneighbors(self, X=None, n_neighbors=None, return_distance=True, return_dataframe_index=False,
+                   use_deterministic_ordering=True):
+        """Neighbours of ``X`` (or of every fitted row, itself excluded, when ``X`` is None);
+        same contract as REF _base.py:111-182.  CUDA tensors in give CUDA tensors out."""
+        check_is_fitted(self, "_fit_X")
+        k = self._resolve_k(n_neighbors)
+        if X is not None:
+            X = self._validate_query(X)
+        dist, idx = self._kneighbors_engine(X, k, apply_affine=False,
+                                            use_deterministic_ordering=use_deterministic_ordering)
+        return self._finish_kneighbors(dist, idx, return_distance, return_dataframe_index)
+
+    def _finish_kneighbors(self, dist, idx, return_distance, return_dataframe_index):
+        if return_dataframe_index:
+            msg = "Dataframe indexes can only be returned when fitted with a dataframe."
+            check_is_fitted(self, "dataframe_index_in_", msg=msg)
+            table = self.dataframe_index_in_
+            if table.dtype.kind in "iu" and table.dtype.itemsize <= 8 and table.dtype != np.uint64:
+                idx = self.engine_.crosswalk(idx, table.astype(np.int64, copy=False)).reshape(idx.shape)
+                if not is_torch_cuda_tensor(idx):
+                    idx = idx.astype(table.dtype, copy=False)
+            else:  # labels that are not 64-bit integers (strings, ...) cannot live on the device
+                host_idx = idx.cpu().numpy() if is_torch_cuda_tensor(idx) else idx
+                idx = table[host_idx]
+        return (dist, idx) if return_distance else idx
+
+    def _predict_engine(self, X, *, apply_affine, row_offset=0, n_self_rows=None):
+        weights = None if self.weights is None else self.weights
+        pred = self.engine_.predict(
+            X, self.n_neighbors, "uniform" if weights is None else weights, exclude_self=X is None,
+            deterministic=True, decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
+            apply_affine=apply_affine, row_offset=row_offset, n_self_rows=n_self_rows)
+        if self._y.ndim == 1:
+            pred = pred.reshape(-1)
+        return pred
+
+    def predict(self, X):
+        """Weighted mean of the neighbours' targets (SKL/neighbors/_regression.py:224-268);
+        ``X=None`` predicts every fitted row from its neighbours, itself excluded."""
+        check_is_fitted(self, "_fit_X")
+        if X is not None:
+            X = self._validate_query(X)
+        try:
+            return self._predict_engine(X, apply_affine=False)
+        except _native.HipBackendError as err:
+            if err.code == _native.ERR_K_TOO_LARGE:
+                raise ValueError(err.message) from None
+            raise
+
+    def score(self, X, y, sample_weight=None):
+        """R^2 of ``predict(X)`` (``X`` may be None as in REF _base.py:40)."""
+        pred = self.predict(X)
+        if is_torch_cuda_tensor(pred):
+            pred = pred.cpu().numpy()
+        return float(r2_score(y, pred, sample_weight=sample_weight))
+
+    def __sklearn_tags__(self):
+        tags = super().__sklearn_tags__()
+        tags.input_tags.sparse = False
+        return tags
+
+
+class TransformedKNeighborsRegressor(BaseEstimator, ABC):
+    """kNN regressors that search in a transformed feature space (REF _base.py:185-358).
+
+    ``fit`` learns the transformer on the host, maps the training rows through the GPU
+    affine kernel, and installs the same map in the engine so that ``kneighbors`` /
+    ``predict`` take *untransformed* rows and transform them inside the launch.
+    """
+
+    def __init__(self, n_neighbors=5, *, weights="uniform", algorithm="auto", leaf_size=30, p=2,
+                 metric="minkowski", metric_params=None, n_jobs=None):
+        self.n_neighbors = n_neighbors
+        self.weights = weights
+        self.algorithm = algorithm
+        self.leaf_size = leaf_size
+        self.p = p
+        self.metric = metric
+        self.metric_params = metric_params
+        self.n_jobs = n_jobs
+
+    @abstractmethod
+    def _get_transformer(self):
+        """The (unfitted) transformer that defines the feature space."""
+
+    def _set_fitted_transformer(self, X, y) -> None:
+        self.transformer_ = self._get_transformer().fit(X, y)
+
+    def _get_additional_regressor_init_kwargs(self) -> dict:
+        return {}
+
+    def _transform_X(self, X):
+        """Host-side transform, kept for API parity (REF _base.py:236-239); the hot path does
+        not use it -- queries are transformed on the device."""
+        check_is_fitted(self, "transformer_")
+        return self.transformer_.transform(X) if X is not None else X
+
+    def fit(self, X, y):
+        validate_data(self, X=X, y=y, ensure_all_finite=True, multi_output=True)
+        self._set_fitted_transformer(X, y)
+
+        center, scale, proj = self.transformer_.affine_params()
+        X_arr = np.ascontiguousarray(
+            validate_data(self.transformer_, X=X, reset=False, dtype=np.float64), dtype=np.float64)
+        device = default_device()
+        X_transformed = _native.affine_transform_host(X_arr, center, scale, proj, device=device)
+
+        kwargs = {
+            "n_neighbors": self.n_neighbors, "weights": self.weights, "algorithm": self.algorithm,
+            "leaf_size": self.leaf_size, "p": self.p, "metric": self.metric,
+            "metric_params": self.metric_params, "n_jobs": self.n_jobs,
+        }
+        kwargs.update(self._get_additional_regressor_init_kwargs())
+        self.regressor_ = RawKNNRegressor(**kwargs)
+        self.regressor_._fit_arrays(X_transformed, y, affine=(X_arr.shape[1], center, scale, proj),
+                                    device=device)
+        self.regressor_._set_dataframe_index_in(X)
+
+        self.n_features_in_ = self.regressor_.n_features_in_
+        self.independent_prediction_ = self.regressor_.independent_prediction_
+        self.independent_score_ = self.regressor_.independent_score_
+        if hasattr(self.regressor_, "dataframe_index_in_"):
+            self.dataframe_index_in_ = self.regressor_.dataframe_index_in_
+        return self
+
+    def _validate_raw_query(self, X):
+        """Same checks the transformer's ``transform`` applies (feature names/count, finiteness)
+        without transforming on the host."""
+        check_is_fitted(self, "transformer_")
+        if is_torch_cuda_tensor(X):
+            d_in = self.regressor_.engine_.d_in
+            if X.ndim != 2 or X.shape[1] != d_in:
+                raise ValueError(f"X has {X.shape[-1]} features, but {type(self).__name__} is expecting "
+                                 f"{d_in} features as input.")
+            return X
+        return validate_data(self.transformer_, X=X, reset=False, dtype=np.float64, order="C",
+                             ensure_all_finite=True)
+
+    def kneighbors(self, X=None, n_neighbors=None, return_distance=True, return_dataframe_index=False,
+                   use_deterministic_ordering=True):
+        """REF _base.py:285-344."""
+        check_is_fitted(self, "regressor_")
+        reg = self.regressor_
+        k = reg._resolve_k(n_neighbors)
+        if X is not None:
+            X = self._validate_raw_query(X)
+        dist, idx = reg._kneighbors_engine(X, k, apply_affine=X is not None,
+                                           use_deterministic_ordering=use_deterministic_ordering)
+        return reg._finish_kneighbors(dist, idx, return_distance, return_dataframe_index)
+
+    def predict(self, X):
+        """REF _base.py:346-348."""
+        check_is_fitted(self, "regressor_")
+        X = self._validate_raw_query(X)
+        try:
+            return self.regressor_._predict_engine(X, apply_affine=True)
+        except _native.HipBackendError as err:
+            if err.code == _native.ERR_K_TOO_LARGE:
+                raise ValueError(err.message) from None
+            raise
+
+    def score(self, X, y):
+        """REF _base.py:350-352."""
+        pred = self.predict(X)
+        if is_torch_cuda_tensor(pred):
+            pred = pred.cpu().numpy()
+        return float(r2_score(y, pred))
+
+    def __sklearn_tags__(self):
+        tags = super().__sklearn_tags__()
+        tags.estimator_type = "regressor"
+        tags.target_tags.multi_output = True
+        tags.input_tags.sparse = False
+        return tags
+
+
+class YFitMixin(TransformedKNeighborsRegressor):
+    """Optional ``y_fit`` that only the transformer sees (REF _base.py:361-374)."""
+
+    def _set_fitted_transformer(self, X, y) -> None:
+        y_fit = self.y_fit_ if self.y_fit_ is not None else y
+        self.transformer_ = self._get_transformer().fit(X, y_fit)
+
+    def fit(self, X, y, y_fit=None):
+        self.y_fit_ = y_fit
+        return super().fit(X, y)
+
+
+class OrdinationKNeighborsRegressor(TransformedKNeighborsRegressor, ABC):
+    """Transformed regressors with an ``n_components`` knob (REF _base.py:377-408)."""
+
+    def __init__(self, n_neighbors=5, *, n_components=None, weights="uniform", algorithm="auto",
+                 leaf_size=30, p=2, metric="minkowski", metric_params=None, n_jobs=None):
+        super().__init__(n_neighbors=n_neighbors, weights=weights, algorithm=algorithm,
+                         leaf_size=leaf_size, p=p, metric=metric, metric_params=metric_params,
+                         n_jobs=n_jobs)
+        self.n_components = n_components
+
+
+__all__ = [
+    "RawKNNRegressor",
+    "TransformedKNeighborsRegressor",
+    "YFitMixin",
+    "OrdinationKNeighborsRegressor",
+    "NotFittedError",
+]

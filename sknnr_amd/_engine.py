@@ -1,0 +1,194 @@
+"""Device engine behind the estimators: one :class:`KNNEngine` per fitted regressor.
+
+It owns the native index handle (reference rows, targets and the query-time affine map
+resident in HBM) and moves queries/results as numpy arrays (staged through PCIe by the
+library) or as PyTorch-ROCm CUDA tensors (zero copy, launched on torch's current stream).
+All arithmetic happens in ``libsknnr_hip.so``; nothing here computes distances.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _native
+
+__all__ = ["KNNEngine", "default_device", "set_default_device", "is_torch_cuda_tensor"]
+
+_default_device: int | None = None
+
+
+def set_default_device(index: int | None) -> None:
+    """Pin new engines to HIP device ``index`` (None = follow LOCAL_RANK / torch)."""
+    global _default_device
+    _default_device = index
+
+
+def default_device() -> int:
+    """Device for new engines: explicit override, else LOCAL_RANK (one process per GPU
+    under ``torch.distributed.run``), else torch's current device, else 0."""
+    if _default_device is not None:
+        return _default_device
+    import torch
+
+    if torch.cuda.is_available():
+        n = torch.cuda.device_count()
+        if "LOCAL_RANK" in os.environ and n > 0:
+            return int(os.environ["LOCAL_RANK"]) % n
+        return torch.cuda.current_device()
+    return 0
+
+
+def is_torch_cuda_tensor(x) -> bool:
+    mod = type(x).__module__
+    return mod.startswith("torch") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+_WEIGHT_MODES = {"uniform": _native.WEIGHTS_UNIFORM, None: _native.WEIGHTS_UNIFORM,
+                 "distance": _native.WEIGHTS_DISTANCE}
+
+
+class KNNEngine:
+    """HBM-resident kNN index + the kneighbors / predict launches.
+
+    Parameters
+    ----------
+    fit_X : (n_ref, d) float64, the *transformed* reference rows (the reference's ``_fit_X``)
+    y : (n_ref, t) targets or None
+    """
+
+    def __init__(self, fit_X, y=None, device: int | None = None):
+        self.device = default_device() if device is None else int(device)
+        self._index = _native.Index(fit_X, y, device=self.device)
+        self.n_ref = self._index.n_ref
+        self.d = self._index.d
+        self.t = self._index.t
+        self.d_in = self.d
+        self.has_affine = False
+
+    def close(self):
+        self._index.close()
+
+    def set_affine(self, d_in, center=None, scale=None, proj=None):
+        self._index.set_affine(int(d_in), center, scale, proj)
+        self.d_in = int(d_in)
+        self.has_affine = True
+
+    def stats(self) -> dict:
+        return self._index.stats()
+
+    def reset_stats(self):
+        self._index.reset_stats()
+
+    # ------------------------------------------------------------------------------------
+    def _opts(self, k, *, exclude_self, deterministic, decimals, formula, apply_affine,
+              weight_mode=_native.WEIGHTS_UNIFORM, row_offset=0):
+        return self._index.make_opts(
+            k, exclude_self=exclude_self, deterministic=deterministic, decimals=decimals,
+            formula=_native.FORMULA_DIRECT if formula == "direct" else _native.FORMULA_EXPANDED,
+            apply_affine=apply_affine, weight_mode=weight_mode, row_offset=row_offset)
+
+    def _check_columns(self, X, apply_affine):
+        want = self.d_in if apply_affine else self.d
+        if X.shape[1] != want:
+            raise ValueError(f"X has {X.shape[1]} features, the engine expects {want}")
+
+    def kneighbors(self, X, k, *, exclude_self=False, deterministic=True, decimals=10,
+                   formula="expanded", apply_affine=False, row_offset=0, n_self_rows=None,
+                   return_distance=True):
+        """Neighbours of the rows of ``X`` (numpy -> numpy, torch.cuda -> torch.cuda), or of
+        the reference rows ``[row_offset, row_offset + n_self_rows)`` when ``X`` is None."""
+        opts = self._opts(k, exclude_self=exclude_self, deterministic=deterministic,
+                          decimals=decimals, formula=formula,
+                          apply_affine=apply_affine and X is not None, row_offset=row_offset)
+        if X is None:
+            if not exclude_self:
+                raise ValueError("X=None requires exclude_self=True")
+            nq = self.n_ref - row_offset if n_self_rows is None else int(n_self_rows)
+            return self._index.kneighbors_host(None, opts, nq=nq, return_distance=return_distance)
+        if is_torch_cuda_tensor(X):
+            import torch
+
+            if X.dtype != torch.float64 or not X.is_contiguous():
+                X = X.to(torch.float64).contiguous()
+            if X.device.index != self.device:
+                raise ValueError(f"X is on cuda:{X.device.index}, the engine on cuda:{self.device}")
+            self._check_columns(X, apply_affine)
+            nq = X.shape[0]
+            idx = torch.empty((nq, k), dtype=torch.int64, device=X.device)
+            dist = torch.empty((nq, k), dtype=torch.float64, device=X.device) if return_distance else None
+            if nq:
+                stream = torch.cuda.current_stream(X.device).cuda_stream
+                self._index.kneighbors_device(X.data_ptr(), nq, opts,
+                                              dist.data_ptr() if dist is not None else 0,
+                                              idx.data_ptr(), stream)
+            return dist, idx
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self._check_columns(X, apply_affine)
+        return self._index.kneighbors_host(X, opts, return_distance=return_distance)
+
+    def predict(self, X, k, weights="uniform", *, exclude_self=False, deterministic=True, decimals=10,
+                formula="expanded", apply_affine=False, row_offset=0, n_self_rows=None):
+        """Weighted multi-output mean of the neighbours' targets."""
+        if self.t < 1:
+            raise ValueError("the engine was built without targets")
+        if callable(weights):
+            # A Python callable cannot run on the device: find the neighbours on the GPU, let
+            # the callable map the (nq, k) distances to weights on the host, reduce on the GPU.
+            dist, idx = self.kneighbors(X, k, exclude_self=exclude_self, deterministic=deterministic,
+                                        decimals=decimals, formula=formula, apply_affine=apply_affine,
+                                        row_offset=row_offset, n_self_rows=n_self_rows)
+            if is_torch_cuda_tensor(dist):
+                import torch
+
+                w = weights(dist)
+                w = torch.as_tensor(w, dtype=torch.float64, device=dist.device).contiguous()
+                pred = torch.empty((dist.shape[0], self.t), dtype=torch.float64, device=dist.device)
+                stream = torch.cuda.current_stream(dist.device).cuda_stream
+                self._index.predict_from_neighbors_device(dist.data_ptr(), idx.data_ptr(), w.data_ptr(),
+                                                          dist.shape[0], k, _native.WEIGHTS_EXPLICIT,
+                                                          pred.data_ptr(), stream)
+                return pred
+            w = np.asarray(weights(dist), dtype=np.float64)
+            if w.shape != dist.shape:
+                raise ValueError("the weights callable must return an array shaped like its input")
+            return self._index.predict_from_neighbors_host(dist, idx, w, _native.WEIGHTS_EXPLICIT)
+        if weights not in _WEIGHT_MODES:
+            raise ValueError(f"weights not recognized: should be 'uniform', 'distance', or a callable; got {weights!r}")
+        mode = _WEIGHT_MODES[weights]
+        opts = self._opts(k, exclude_self=exclude_self, deterministic=deterministic, decimals=decimals,
+                          formula=formula, apply_affine=apply_affine and X is not None,
+                          weight_mode=mode, row_offset=row_offset)
+        if X is None:
+            nq = self.n_ref - row_offset if n_self_rows is None else int(n_self_rows)
+            return self._index.predict_host(None, opts, nq=nq)
+        if is_torch_cuda_tensor(X):
+            import torch
+
+            if X.dtype != torch.float64 or not X.is_contiguous():
+                X = X.to(torch.float64).contiguous()
+            self._check_columns(X, apply_affine)
+            nq = X.shape[0]
+            pred = torch.empty((nq, self.t), dtype=torch.float64, device=X.device)
+            if nq:
+                stream = torch.cuda.current_stream(X.device).cuda_stream
+                self._index.predict_device(X.data_ptr(), nq, opts, pred.data_ptr(), 0, 0, stream)
+            return pred
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self._check_columns(X, apply_affine)
+        return self._index.predict_host(X, opts)
+
+    def crosswalk(self, idx, table):
+        """``table[idx]`` for int64 dataframe ids (REF _base.py:177-180)."""
+        if is_torch_cuda_tensor(idx):
+            import torch
+
+            tab = torch.as_tensor(np.ascontiguousarray(table, dtype=np.int64), device=idx.device)
+            out = torch.empty_like(idx)
+            stream = torch.cuda.current_stream(idx.device).cuda_stream
+            _native.crosswalk_device(tab.data_ptr(), tab.numel(), idx.data_ptr(), idx.numel(),
+                                     out.data_ptr(), self.device, stream)
+            torch.cuda.current_stream(idx.device).synchronize()  # tab dies with this frame
+            return out
+        return _native.crosswalk_host(table, idx, self.device)

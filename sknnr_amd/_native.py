@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "sknnr_index_create",
     "sknnr_index_destroy",
     "sknnr_index_set_affine",
+    "sknnr_affine_transform",
     "sknnr_index_shape",
     "sknnr_get_stats",
     "sknnr_reset_stats",
@@ -124,6 +125,7 @@ def load(build_if_missing: bool = False):
     lib.sknnr_index_destroy.argtypes = [vp]
     lib.sknnr_index_destroy.restype = None
     lib.sknnr_index_set_affine.argtypes = [vp, c_int32, vp, vp, vp]
+    lib.sknnr_affine_transform.argtypes = [vp, c_int64, c_int32, vp, vp, vp, c_int32, vp, c_int32]
     lib.sknnr_index_shape.argtypes = [vp, POINTER(c_int64), POINTER(c_int32), POINTER(c_int32),
                                       POINTER(c_int32), POINTER(c_int32)]
     lib.sknnr_get_stats.argtypes = [vp, POINTER(Stats)]
@@ -282,6 +284,18 @@ class Index:
         check(load().sknnr_debug_coarse_matrix(self.handle, _host_ptr(q), nq, _host_ptr(out),
                                                _host_ptr(qn), byref(s), byref(eps)))
         return out, qn, s.value, eps.value
+
+
+def affine_transform_host(x, center=None, scale=None, proj=None, device: int = 0) -> np.ndarray:
+    """``((x - center) / scale) @ proj`` on the GPU (float64 fma chains), host in / host out."""
+    x = _c_f64(x)
+    center, scale, proj = _c_f64(center), _c_f64(scale), _c_f64(proj)
+    n, d_in = x.shape
+    d = d_in if proj is None else proj.shape[1]
+    out = np.empty((n, d), dtype=np.float64)
+    check(load().sknnr_affine_transform(_host_ptr(x), n, d_in, _host_ptr(center), _host_ptr(scale),
+                                        _host_ptr(proj), d, _host_ptr(out), device))
+    return out
 
 
 def crosswalk_host(table, idx, device: int = 0):

@@ -39,7 +39,7 @@ struct PrepArgs {
     const double* mu;      // (dp) zero padded centre of the coarse image
     double s;              // power-of-two scale of the coarse image
     double* xt;            // (nq, d) transformed rows out, or null
-    uint4* qimg;           // [nq_pad/32][2][ks][64] fragments out
+    uint4* qimg;           // [nq_pad/32][2][ks][64] fragments out, or null (transform only)
     double* qnc;           // (nq) out
 };
 
@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
                 }
             }
         }
+        if (!a.qimg) continue;  // transform-only launch (sknnr_affine_transform)
         half8 hi, lo;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
             a.qimg[((size_t)(qb * 2 + 1) * a.ks + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, lo);
         }
     }
-    if (live) a.qnc[q] = qn;
+    if (live && a.qnc) a.qnc[q] = qn;
 }
 
 // ---------------------------------------------------------------------------------------

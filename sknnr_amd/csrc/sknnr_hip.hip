@@ -362,6 +362,85 @@ extern "C" int sknnr_index_set_affine(sknnr_index* ix, int32_t d_in, const doubl
     return SKNNR_OK;
 }
 
+extern "C" int sknnr_affine_transform(const double* x, int64_t n, int32_t d_in, const double* center,
+                                      const double* scale, const double* proj, int32_t d, double* out,
+                                      int32_t device) {
+    if (!x || !out || n < 0 || d_in < 1 || d < 1) return fail(SKNNR_ERR_INVALID, "bad argument");
+    if (!proj && d_in != d) return fail(SKNNR_ERR_INVALID, "without a projection d_in (%d) must equal d (%d)", d_in, d);
+    if (n == 0) return SKNNR_OK;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(SKNNR_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= n_dev) return fail(SKNNR_ERR_INVALID, "device %d out of range [0, %d)", device, n_dev);
+    HIP_TRY(hipSetDevice(device));
+    const int ks = (d + 15) / 16, dp = 16 * ks;
+    if ((size_t)64 * (d_in | 1) * 8 > 150 * 1024)
+        return fail(SKNNR_ERR_UNSUPPORTED, "d_in = %d is too wide for the transform kernel (max 299)", d_in);
+    DevBuf<double> dx, dc, dsc, dpj, dout;
+    int rc = SKNNR_OK;
+    auto cleanup = [&]() { dx.release(); dc.release(); dsc.release(); dpj.release(); dout.release(); };
+#define AT_TRY(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            cleanup();                                                                                \
+            return fail(SKNNR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                \
+        }                                                                                             \
+    } while (0)
+    std::vector<double> padded;
+    if (proj) {
+        padded.assign((size_t)d_in * dp, 0.0);
+        for (int c = 0; c < d_in; ++c)
+            for (int j = 0; j < d; ++j) padded[(size_t)c * dp + j] = proj[(size_t)c * d + j];
+        AT_TRY(dpj.ensure(padded.size()));
+        AT_TRY(hipMemcpy(dpj.p, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (center) {
+        AT_TRY(dc.ensure(d_in));
+        AT_TRY(hipMemcpy(dc.p, center, d_in * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (scale) {
+        AT_TRY(dsc.ensure(d_in));
+        AT_TRY(hipMemcpy(dsc.p, scale, d_in * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const long rows = std::min<long>(n, kChunkRows);
+    AT_TRY(dx.ensure((size_t)rows * d_in));
+    AT_TRY(dout.ensure((size_t)rows * d));
+    for (long c0 = 0; c0 < n; c0 += rows) {
+        const long m = std::min<long>(rows, n - c0);
+        AT_TRY(hipMemcpy(dx.p, x + c0 * d_in, (size_t)m * d_in * sizeof(double), hipMemcpyHostToDevice));
+        PrepArgs a{};
+        a.x = dx.p;
+        a.nq = m;
+        a.nq_pad = (m + 255) / 256 * 256;
+        a.d_in = d_in;
+        a.d = d;
+        a.ks = ks;
+        a.center = center ? dc.p : nullptr;
+        a.scale = scale ? dsc.p : nullptr;
+        a.proj = proj ? dpj.p : nullptr;
+        a.xt = dout.p;
+        const int ldx = d_in | 1;
+        if ((size_t)256 * ldx * 8 <= 150 * 1024) {
+            const size_t sh = (size_t)256 * ldx * 8;
+            AT_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            prep_queries_kernel<256><<<dim3((unsigned)(a.nq_pad / 256)), dim3(256), sh>>>(a);
+        } else if ((size_t)128 * ldx * 8 <= 150 * 1024) {
+            const size_t sh = (size_t)128 * ldx * 8;
+            AT_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            prep_queries_kernel<128><<<dim3((unsigned)(a.nq_pad / 128)), dim3(128), sh>>>(a);
+        } else {
+            const size_t sh = (size_t)64 * ldx * 8;
+            AT_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            prep_queries_kernel<64><<<dim3((unsigned)(a.nq_pad / 64)), dim3(64), sh>>>(a);
+        }
+        AT_TRY(hipGetLastError());
+        AT_TRY(hipMemcpy(out + c0 * d, dout.p, (size_t)m * d * sizeof(double), hipMemcpyDeviceToHost));
+    }
+#undef AT_TRY
+    cleanup();
+    return rc;
+}
+
 // ----------------------------------------------------------------------------------------
 // stats
 // ----------------------------------------------------------------------------------------

@@ -1,0 +1,243 @@
+"""Row-sharded kneighbors / predict over the GPUs of one node.
+
+One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on ROCm,
+``gloo`` in the CPU tests).  Every rank holds the same fitted estimator (the reference set
+is tiny next to 288 GB of HBM: 50k x 64 float64 = 25.6 MB) and answers a *contiguous* block
+of the query rows, carrying the block's global row offset so that sknnr's position-dependent
+tie-break (``|idx - row|``, /root/reference/src/sknnr/_base.py:171) is identical to the
+single-call result.  Each shard's result is final -- the only exchange step is the
+all-gather of the per-shard ``(dist, idx)`` blocks (and predictions); the "merge" is
+concatenation in rank order.
+
+xGMI is point to point (7 links per GPU): every rank contributes one block and receives
+W-1 blocks, one per link, so the gather of chunk ``i`` is issued on a side stream and
+overlaps the kernels of chunk ``i+1``; nothing in the data path is a ring of dependent hops.
+"""
+
+from __future__ import annotations
+
+from typing import Callable
+
+import numpy as np
+
+__all__ = ["shard_bounds", "all_gather_rows", "ShardedKNN"]
+
+
+def shard_bounds(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous, balanced block of ``rank``: the first ``n % W`` ranks get one extra row."""
+    base, rem = divmod(int(n_rows), int(world_size))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def _max_rows(n_rows: int, world_size: int) -> int:
+    return -(-int(n_rows) // int(world_size))
+
+
+def all_gather_rows(local, n_rows_total: int, group=None, async_op: bool = False):
+    """Concatenate the ranks' row blocks (sizes given by :func:`shard_bounds`) on every rank.
+
+    ``local`` is a torch tensor (CUDA under nccl, CPU under gloo) whose rows are this rank's
+    block.  Blocks are padded to the common maximum for the collective and trimmed after.
+    Returns the gathered tensor, or ``(finish, work)`` when ``async_op`` is set, where
+    ``finish()`` waits and returns it.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    pad_rows = _max_rows(n_rows_total, world)
+    tail = tuple(local.shape[1:])
+    send = local
+    if local.shape[0] != pad_rows:
+        send = torch.zeros((pad_rows, *tail), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    send = send.contiguous()
+    recv = torch.empty((world * pad_rows, *tail), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+
+    def finish():
+        if work is not None:
+            work.wait()
+        if n_rows_total == world * pad_rows:
+            return recv
+        parts = []
+        for r in range(world):
+            a, b = shard_bounds(n_rows_total, world, r)
+            parts.append(recv[r * pad_rows : r * pad_rows + (b - a)])
+        return torch.cat(parts, dim=0)
+
+    return (finish, work) if async_op else finish()
+
+
+class ShardedKNN:
+    """Query-row sharding of a fitted estimator across the ranks of ``group``.
+
+    Parameters
+    ----------
+    estimator : a fitted ``sknnr_amd`` estimator (every rank fits/loads the same one), or None
+        together with explicit ``local_kneighbors`` / ``local_predict`` callables.
+    local_kneighbors : ``f(X_block, row_offset, n_neighbors, **kw) -> (dist, idx)`` override
+        (the CPU tests plug the oracle in here; the product path uses the estimator's engine).
+    local_predict : ``f(X_block, row_offset) -> pred`` override.
+    """
+
+    def __init__(self, estimator=None, group=None, local_kneighbors: Callable | None = None,
+                 local_predict: Callable | None = None):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
+        self.estimator = estimator
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        self._local_kneighbors = local_kneighbors or self._engine_kneighbors
+        self._local_predict = local_predict or self._engine_predict
+
+    # ---- local engines ------------------------------------------------------------------
+    def _reg(self):
+        est = self.estimator
+        return getattr(est, "regressor_", est), hasattr(est, "regressor_")
+
+    def _engine_kneighbors(self, X_block, row_offset, n_neighbors, use_deterministic_ordering=True,
+                           n_self_rows=None):
+        reg, transformed = self._reg()
+        k = reg._resolve_k(n_neighbors)
+        return reg._kneighbors_engine(X_block, k, apply_affine=transformed and X_block is not None,
+                                      use_deterministic_ordering=use_deterministic_ordering,
+                                      row_offset=row_offset, n_self_rows=n_self_rows)
+
+    def _engine_predict(self, X_block, row_offset, n_self_rows=None):
+        reg, transformed = self._reg()
+        return reg._predict_engine(X_block, apply_affine=transformed and X_block is not None,
+                                   row_offset=row_offset, n_self_rows=n_self_rows)
+
+    # ---- helpers --------------------------------------------------------------------------
+    def local_bounds(self, n_rows: int) -> tuple[int, int]:
+        return shard_bounds(n_rows, self.world_size, self.rank)
+
+    def _as_comm_tensor(self, a):
+        import torch
+        import torch.distributed as dist
+
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a))
+        if dist.get_backend(self.group) == "nccl" and not t.is_cuda:
+            t = t.cuda()
+        return t
+
+    # ---- public ---------------------------------------------------------------------------
+    def kneighbors(self, X=None, n_neighbors=None, *, n_rows_total=None, X_is_local_block=False,
+                   use_deterministic_ordering=True, gather=True, **kw):
+        """Neighbours of all query rows, computed one block per rank.
+
+        ``X`` is either the whole query matrix (every rank slices its block) or, with
+        ``X_is_local_block=True``, already this rank's block of a call of ``n_rows_total`` rows.
+        ``X=None`` shards the fit-time self query (the reference's ``X=None`` path) over the
+        reference rows.  With ``gather=False`` only the local block is returned.
+        """
+        if X is None:
+            n_rows_total = self._reg()[0].n_samples_fit_ if n_rows_total is None else n_rows_total
+            a, b = self.local_bounds(n_rows_total)
+            dist_l, idx_l = self._local_kneighbors(None, a, n_neighbors, n_self_rows=b - a,
+                                                   use_deterministic_ordering=use_deterministic_ordering, **kw)
+        else:
+            if X_is_local_block:
+                if n_rows_total is None:
+                    raise ValueError("n_rows_total is required with X_is_local_block=True")
+                a, b = self.local_bounds(n_rows_total)
+                block = X
+                if block.shape[0] != b - a:
+                    raise ValueError(f"rank {self.rank} expects {b - a} rows, got {block.shape[0]}")
+            else:
+                n_rows_total = X.shape[0]
+                a, b = self.local_bounds(n_rows_total)
+                block = X[a:b]
+            dist_l, idx_l = self._local_kneighbors(block, a, n_neighbors,
+                                                   use_deterministic_ordering=use_deterministic_ordering, **kw)
+        if not gather or self.world_size == 1:
+            return dist_l, idx_l
+        as_numpy = isinstance(idx_l, np.ndarray)
+        d_all = all_gather_rows(self._as_comm_tensor(dist_l), n_rows_total, self.group)
+        i_all = all_gather_rows(self._as_comm_tensor(idx_l), n_rows_total, self.group)
+        if as_numpy:
+            return d_all.cpu().numpy(), i_all.cpu().numpy()
+        return d_all, i_all
+
+    def predict(self, X=None, *, n_rows_total=None, X_is_local_block=False, gather=True):
+        """Predictions of all query rows, one block per rank, all-gathered."""
+        if X is None:
+            n_rows_total = self._reg()[0].n_samples_fit_ if n_rows_total is None else n_rows_total
+            a, b = self.local_bounds(n_rows_total)
+            pred_l = self._local_predict(None, a, n_self_rows=b - a)
+        else:
+            if X_is_local_block:
+                if n_rows_total is None:
+                    raise ValueError("n_rows_total is required with X_is_local_block=True")
+                a, b = self.local_bounds(n_rows_total)
+                block = X
+            else:
+                n_rows_total = X.shape[0]
+                a, b = self.local_bounds(n_rows_total)
+                block = X[a:b]
+            pred_l = self._local_predict(block, a)
+        if not gather or self.world_size == 1:
+            return pred_l
+        as_numpy = isinstance(pred_l, np.ndarray)
+        p_all = all_gather_rows(self._as_comm_tensor(pred_l), n_rows_total, self.group)
+        return p_all.cpu().numpy() if as_numpy else p_all
+
+    def kneighbors_pipelined(self, X_block, n_rows_total, n_neighbors=None, *, chunk_rows=1 << 21,
+                             use_deterministic_ordering=True):
+        """Device-resident block in, gathered ``(dist, idx)`` of the whole call out, with the
+        all-gather of chunk ``i`` overlapping the kernels of chunk ``i+1`` (nccl/RCCL only).
+
+        Chunks are cut at the same row positions on every rank (blocks are padded to the common
+        maximum), so every collective has equal sizes everywhere.
+        """
+        import torch
+
+        a, b = self.local_bounds(n_rows_total)
+        n_local = b - a
+        pad_rows = _max_rows(n_rows_total, self.world_size)
+        reg = self._reg()[0]
+        k = reg._resolve_k(n_neighbors)
+        dev = X_block.device
+        comm = torch.cuda.Stream(device=dev)
+        compute = torch.cuda.current_stream(dev)
+        pending = []
+        for c0 in range(0, pad_rows, chunk_rows):
+            c1 = min(pad_rows, c0 + chunk_rows)
+            lo, hi = min(c0, n_local), min(c1, n_local)
+            d_c = torch.zeros((c1 - c0, k), dtype=torch.float64, device=dev)
+            i_c = torch.zeros((c1 - c0, k), dtype=torch.int64, device=dev)
+            if hi > lo:
+                d_l, i_l = self._local_kneighbors(X_block[lo:hi], a + lo, k,
+                                                  use_deterministic_ordering=use_deterministic_ordering)
+                d_c[: hi - lo] = d_l
+                i_c[: hi - lo] = i_l
+            ready = torch.cuda.Event()
+            ready.record(compute)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                d_all = torch.empty((self.world_size * (c1 - c0), k), dtype=torch.float64, device=dev)
+                i_all = torch.empty((self.world_size * (c1 - c0), k), dtype=torch.int64, device=dev)
+                import torch.distributed as dist
+
+                w1 = dist.all_gather_into_tensor(d_all, d_c, group=self.group, async_op=True)
+                w2 = dist.all_gather_into_tensor(i_all, i_c, group=self.group, async_op=True)
+            pending.append((c0, c1, d_c, i_c, d_all, i_all, w1, w2))
+        out_d = torch.empty((n_rows_total, k), dtype=torch.float64, device=dev)
+        out_i = torch.empty((n_rows_total, k), dtype=torch.int64, device=dev)
+        for c0, c1, _d_c, _i_c, d_all, i_all, w1, w2 in pending:
+            w1.wait()
+            w2.wait()
+            rows = c1 - c0
+            for r in range(self.world_size):
+                ra, rb = shard_bounds(n_rows_total, self.world_size, r)
+                lo, hi = min(c0, rb - ra), min(c1, rb - ra)
+                if hi > lo:
+                    out_d[ra + lo : ra + hi] = d_all[r * rows : r * rows + (hi - lo)]
+                    out_i[ra + lo : ra + hi] = i_all[r * rows : r * rows + (hi - lo)]
+        compute.wait_stream(comm)
+        return out_d, out_i

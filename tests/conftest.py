@@ -1,0 +1,80 @@
+"""Shared test configuration.
+
+``-m "not gpu"``: oracle vs golden vectors, host logic, C-ABI load/export checks, gloo
+sharding -- runs anywhere.  ``-m gpu``: parity of the HIP path against the oracle and the
+golden vectors, through the C ABI -- needs an MI355X.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name: str):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def moscow():
+    """Moscow Mountain / St. Joes with the reference tests' fixed 80/20 unshuffled split
+    (/root/reference/tests/conftest.py:45-59): 132 train / 33 test rows."""
+    from sknnr_amd.datasets import load_moscow_stjoes
+
+    ds = load_moscow_stjoes()
+    n_train = 132
+    return {
+        "X_train": ds.data[:n_train], "X_test": ds.data[n_train:],
+        "y_train": ds.target[:n_train], "y_test": ds.target[n_train:],
+        "index": ds.index, "feature_names": ds.feature_names, "target_names": ds.target_names,
+    }
+
+
+@pytest.fixture(scope="session")
+def moscow_frames():
+    from sknnr_amd.datasets import load_moscow_stjoes
+
+    X, y = load_moscow_stjoes(return_X_y=True, as_frame=True)
+    return {"X_train": X.iloc[:132], "X_test": X.iloc[132:], "y_train": y.iloc[:132], "y_test": y.iloc[132:]}
+
+
+def yaimpute_weights(d):
+    """The callable the reference's regression tests use (tests/test_regressions.py:31-39)."""
+    return 1.0 / (1.0 + d)
+
+
+def assert_neighbors_match(idx, dist, ref_idx, ref_dist, fit_X=None, rtol=1e-5, atol=1e-8):
+    """Indices must be identical, except where the reference itself is arbitrary: two
+    *bitwise identical* reference rows tied for a slot (the pick then depends on OpenBLAS
+    kernel position effects / kd-tree visiting order).  Distances within the reference's own
+    regression tolerance (pytest-regressions defaults rtol 1e-5, atol 1e-8)."""
+    idx, ref_idx = np.asarray(idx), np.asarray(ref_idx)
+    np.testing.assert_allclose(np.asarray(dist), np.asarray(ref_dist), rtol=rtol, atol=atol)
+    bad = idx != ref_idx
+    if not bad.any():
+        return 0
+    assert fit_X is not None, f"{int(bad.sum())} neighbour indices differ"
+    rows, cols = np.nonzero(bad)
+    for r, c in zip(rows, cols):
+        a, b = int(idx[r, c]), int(ref_idx[r, c])
+        same_row = np.array_equal(fit_X[a], fit_X[b])
+        # the two answers may also hold the same tied set in a different order
+        same_set = sorted(idx[r].tolist()) == sorted(ref_idx[r].tolist())
+        if not (same_row or same_set):
+            raise AssertionError(f"row {r}: neighbour {c} is {a}, reference says {b} (rows differ)")
+        if same_set and not same_row:
+            raise AssertionError(f"row {r}: same neighbours in a different order: {idx[r]} vs {ref_idx[r]}")
+    return int(bad.sum())

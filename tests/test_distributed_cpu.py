@@ -1,0 +1,105 @@
+"""The N>1 path on CPU: two gloo ranks shard the query rows, each answers its block with the
+oracle as the local engine (tests may use the oracle; the product path uses the HIP engine
+through the same ShardedKNN), results are all-gathered and must equal the single-call answer
+-- including the reorder's global row offset and uneven blocks."""
+
+from __future__ import annotations
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_q, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from sknnr_amd import synth
+    from sknnr_amd.distributed import ShardedKNN, shard_bounds
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x_ref, y, x_q = synth.make_problem(300, n_q, 6, t=3, n_dup_refs=20, n_dup_queries=10)
+        x_q[1] = x_q[0]  # identical queries at different rows: the |idx - row| key matters
+
+        def local_kn(block, row_offset, k, use_deterministic_ordering=True, n_self_rows=None):
+            if block is None:
+                d, i = O.argkmin(x_ref[row_offset:row_offset + n_self_rows], x_ref, k + 1, "expanded")
+                d, i = O.drop_self(d, i, row_offset)
+                return O.deterministic_reorder(d, i, 10, row_offset) if use_deterministic_ordering else (d, i)
+            return O.kneighbors(x_ref, block, k, "expanded", deterministic=use_deterministic_ordering,
+                                row_offset=row_offset)
+
+        def local_pred(block, row_offset, n_self_rows=None):
+            d, i = local_kn(block, row_offset, 4, n_self_rows=n_self_rows)
+            return O.predict(y, d, i, "distance")
+
+        sh = ShardedKNN(None, local_kneighbors=local_kn, local_predict=local_pred)
+        d_all, i_all = sh.kneighbors(x_q, 4)
+        a, b = shard_bounds(n_q, world, rank)
+        d_blk, i_blk = sh.kneighbors(x_q[a:b], 4, n_rows_total=n_q, X_is_local_block=True)
+        d_self, i_self = sh.kneighbors(None, 4, n_rows_total=300)
+        p_all = sh.predict(x_q)
+        p_self = sh.predict(None, n_rows_total=300)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), d_all=d_all, i_all=i_all, d_blk=d_blk, i_blk=i_blk,
+                 d_self=d_self, i_self=i_self, p_all=p_all, p_self=p_self)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_q", [64, 37])
+def test_two_rank_sharding_matches_single_call(tmp_path, n_q):
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as O
+    from sknnr_amd import synth
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_q, str(tmp_path)), nprocs=world, join=True)
+
+    x_ref, y, x_q = synth.make_problem(300, n_q, 6, t=3, n_dup_refs=20, n_dup_queries=10)
+    x_q[1] = x_q[0]
+    d, i = O.kneighbors(x_ref, x_q, 4, "expanded")
+    ds, is_ = O.kneighbors(x_ref, None, 4, "expanded")
+    for rank in range(world):
+        r = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        np.testing.assert_array_equal(r["i_all"], i)
+        np.testing.assert_array_equal(r["d_all"], d)
+        np.testing.assert_array_equal(r["i_blk"], i)
+        np.testing.assert_array_equal(r["d_blk"], d)
+        np.testing.assert_array_equal(r["i_self"], is_)
+        np.testing.assert_array_equal(r["d_self"], ds)
+        np.testing.assert_array_equal(r["p_all"], O.predict(y, d, i, "distance"))
+        np.testing.assert_array_equal(r["p_self"], O.predict(y, ds, is_, "distance"))
+
+
+def test_shard_bounds_partition_the_rows():
+    from sknnr_amd.distributed import shard_bounds
+
+    for n in (0, 1, 7, 8, 9, 10_000_000, 50_000_001):
+        for w in (1, 2, 4, 8):
+            edges = [shard_bounds(n, w, r) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(w - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sharded_needs_an_initialised_group():
+    from sknnr_amd.distributed import ShardedKNN
+
+    with pytest.raises(RuntimeError, match="not initialised"):
+        ShardedKNN(None)

@@ -1,0 +1,271 @@
+"""GPU tests of the estimator surface: the reference's own regression files and API
+behaviour tests (tests/test_regressions.py, tests/test_estimators.py), re-written against
+``sknnr_amd`` -- same inputs, same expected values."""
+
+from __future__ import annotations
+
+import pickle
+
+import numpy as np
+import pytest
+from sklearn.exceptions import NotFittedError
+
+from conftest import assert_neighbors_match, load_golden, yaimpute_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import sknnr_amd
+    from sknnr_amd import _native
+
+    assert _native.device_count() >= 1
+    return sknnr_amd
+
+
+def _estimators(E):
+    return {
+        "raw": (E.RawKNNRegressor, {}), "euclidean": (E.EuclideanKNNRegressor, {}),
+        "mahalanobis": (E.MahalanobisKNNRegressor, {}), "gnn": (E.GNNRegressor, {}),
+        "msn": (E.MSNRegressor, {}),
+    }
+
+
+CASES = [("raw", None), ("euclidean", None), ("mahalanobis", None), ("gnn", None), ("gnn", 3), ("msn", None), ("msn", 3)]
+
+
+@pytest.mark.parametrize(("name", "n_components"), CASES)
+@pytest.mark.parametrize("reference", [True, False], ids=["reference", "target"])
+def test_reference_regression_files_kneighbors(E, moscow_frames, name, n_components, reference):
+    """REF tests/test_regressions.py:57-86 against the reference's own .npz data."""
+    cls, kw = _estimators(E)[name]
+    if n_components is not None:
+        kw = dict(kw, n_components=n_components)
+    est = cls(n_neighbors=5, **kw).fit(moscow_frames["X_train"], moscow_frames["y_train"])
+    size = "reduced" if n_components else "full"
+    which = "reference" if reference else "target"
+    X = None if reference else moscow_frames["X_test"]
+    for ids in (True, False):
+        dist, nn = est.kneighbors(X, return_dataframe_index=ids)
+        r = load_golden(f"ref_regressions/test_kneighbors_{which}_{size}_{name}_k5_{'ids' if ids else 'index'}_.npz")
+        assert nn.dtype == r["nn"].dtype
+        assert_neighbors_match(nn, dist, r["nn"], r["dist"])
+
+
+@pytest.mark.parametrize(("name", "n_components"), CASES)
+@pytest.mark.parametrize("weighted", [True, False], ids=["weighted", "unweighted"])
+def test_reference_regression_files_predict(E, moscow_frames, name, n_components, weighted):
+    """REF tests/test_regressions.py:89-122."""
+    cls, kw = _estimators(E)[name]
+    if n_components is not None:
+        kw = dict(kw, n_components=n_components)
+    weights = yaimpute_weights if weighted else "uniform"
+    est = cls(n_neighbors=5, weights=weights, **kw).fit(moscow_frames["X_train"], moscow_frames["y_train"])
+    size = "reduced" if n_components else "full"
+    wname = "weighted" if weighted else "unweighted"
+    r = load_golden(f"ref_regressions/test_predict_reference_{wname}_{size}_{name}_k5_.npz")
+    np.testing.assert_allclose(est.independent_prediction_, r["pred"], rtol=1e-5, atol=1e-8)
+    assert est.independent_score_ == pytest.approx(float(r["score"]), rel=1e-5)
+    r = load_golden(f"ref_regressions/test_predict_target_{wname}_{size}_{name}_k5_.npz")
+    np.testing.assert_allclose(est.predict(moscow_frames["X_test"]), r["pred"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["raw", "euclidean", "mahalanobis", "gnn_full", "gnn_reduced", "msn_full", "msn_reduced"])
+def test_extended_moscow_goldens(E, moscow_frames, name):
+    """Vectors generated from the reference (tests/golden/make_golden.py): k in {1,5,7},
+    'distance' weights, deterministic ordering off, fitted transform matrices."""
+    g = load_golden(f"moscow_{name}.npz")
+    base = name.split("_")[0]
+    cls, kw = _estimators(E)[base]
+    if name.endswith("reduced"):
+        kw = dict(kw, n_components=3)
+    Xtr, ytr, Xte = moscow_frames["X_train"], moscow_frames["y_train"], moscow_frames["X_test"]
+    for k in (1, 5, 7):
+        est = cls(n_neighbors=k, **kw).fit(Xtr, ytr)
+        reg = getattr(est, "regressor_", est)
+        if k == 5:
+            assert reg._fit_method == str(g["fit_method"])
+            assert est.n_features_in_ == int(g["n_features_in_"])
+            if hasattr(est, "transformer_"):
+                for attr in ("projector_", "env_center_", "transform_"):
+                    if "tr_" + attr in g:
+                        np.testing.assert_allclose(getattr(est.transformer_, attr), g["tr_" + attr], rtol=1e-8, atol=1e-10)
+                np.testing.assert_allclose(reg._fit_X, g["Xt_train"], rtol=1e-9, atol=1e-10)
+        d, i = est.kneighbors()
+        assert_neighbors_match(i, d, g[f"kn_ref_k{k}_nn"], g[f"kn_ref_k{k}_dist"])
+        d, i = est.kneighbors(Xte)
+        assert_neighbors_match(i, d, g[f"kn_tgt_k{k}_nn"], g[f"kn_tgt_k{k}_dist"])
+        np.testing.assert_array_equal(est.kneighbors(Xte, return_distance=False, return_dataframe_index=True),
+                                      g[f"kn_tgt_k{k}_ids"])
+        if k == 5:
+            d, i = est.kneighbors(Xte, use_deterministic_ordering=False)
+            assert_neighbors_match(i, d, g["kn_tgt_k5_nd_nn"], g["kn_tgt_k5_nd_dist"])
+            np.testing.assert_allclose(est.predict(Xte), g["pred_tgt_uniform"], rtol=1e-5, atol=1e-8)
+            assert est.score(Xte, moscow_frames["y_test"]) == pytest.approx(float(g["score_tgt_uniform"]), rel=1e-5)
+    for wname, w in (("distance", "distance"), ("yaimpute", yaimpute_weights)):
+        for k in (5, 7):
+            est = cls(n_neighbors=k, weights=w, **kw).fit(Xtr, ytr)
+            np.testing.assert_allclose(est.independent_prediction_, g[f"indep_pred_{wname}_k{k}"], rtol=1e-5, atol=1e-8)
+            assert est.independent_score_ == pytest.approx(float(g[f"indep_score_{wname}_k{k}"]), rel=1e-5)
+            np.testing.assert_allclose(est.predict(Xte), g[f"pred_tgt_{wname}_k{k}"], rtol=1e-5, atol=1e-8)
+
+
+def test_baseline_config_1_msn_on_swo(E):
+    """BASELINE.json configs[0]: MSNRegressor on load_swo_ecoplot(), k=5."""
+    from sknnr_amd.datasets import load_swo_ecoplot
+
+    g = load_golden("swo_msn_k5.npz")
+    X, y = load_swo_ecoplot(return_X_y=True, as_frame=True)
+    est = E.MSNRegressor(n_neighbors=5).fit(X, y)
+    assert est.n_features_in_ == int(g["n_features_in_"]) == 17
+    assert est.regressor_._fit_method == str(g["fit_method"]) == "brute"
+    assert est.independent_score_ == pytest.approx(float(g["indep_score"]), rel=1e-7)
+    assert est.independent_score_ == pytest.approx(0.15023, abs=1e-5)
+    np.testing.assert_allclose(est.independent_prediction_[::16], g["indep_pred_rows"], rtol=1e-5, atol=1e-8)
+    d, i = est.kneighbors()
+    assert_neighbors_match(i, d, g["kn_ref_nn"], g["kn_ref_dist"])
+    d, i = est.kneighbors(X)
+    assert_neighbors_match(i, d, g["kn_self_nn"], g["kn_self_dist"], atol=1e-6)
+    np.testing.assert_allclose(est.predict(X)[::16], g["pred_rows"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["euclidean", "mahalanobis", "gnn", "msn"])
+def test_synthetic_estimator_goldens(E, name):
+    """Small versions of BASELINE configs 2-5 on the synthetic law, fitted by the reference."""
+    from sknnr_amd import synth
+
+    g = load_golden(f"synth_est_{name}.npz")
+    cfg = {
+        "euclidean": (E.EuclideanKNNRegressor, dict(n_neighbors=5), "linear"),
+        "mahalanobis": (E.MahalanobisKNNRegressor, dict(n_neighbors=5), "linear"),
+        "gnn": (E.GNNRegressor, dict(n_neighbors=7, weights="distance"), "positive"),
+        "msn": (E.MSNRegressor, dict(n_neighbors=1, n_components=8), "linear"),
+    }[name]
+    x_ref, y, x_q = synth.make_problem(1500, 512, 16, t=20, kind=cfg[2])
+    est = cfg[0](**cfg[1]).fit(x_ref, y)
+    assert est.n_features_in_ == int(g["n_features_in_"])
+    assert est.regressor_._fit_method == str(g["fit_method"])
+    d, i = est.kneighbors(x_q)
+    assert_neighbors_match(i, d, g["nn"], g["dist"])
+    np.testing.assert_allclose(est.predict(x_q), g["pred"], rtol=1e-5, atol=1e-8)
+    assert est.independent_score_ == pytest.approx(float(g["indep_score"]), rel=1e-6)
+    np.testing.assert_allclose(est.independent_prediction_[::8], g["indep_pred_rows"], rtol=1e-5, atol=1e-8)
+
+
+# ---- API behaviour (REF tests/test_estimators.py:156-378) ----------------------------------
+
+ALL = ["raw", "euclidean", "mahalanobis", "gnn", "msn"]
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_not_fitted_raises(E, moscow, name):
+    cls, kw = _estimators(E)[name]
+    with pytest.raises(NotFittedError):
+        cls(**kw).kneighbors(moscow["X_train"])
+    with pytest.raises(NotFittedError):
+        cls(**kw).predict(moscow["X_train"])
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_dataframe_indexes(E, name):
+    """REF tests/test_estimators.py:181-201."""
+    from sknnr_amd.datasets import load_moscow_stjoes
+
+    cls, kw = _estimators(E)[name]
+    est = cls(n_neighbors=1, **kw)
+    ds = load_moscow_stjoes()
+    X_df, _ = load_moscow_stjoes(as_frame=True, return_X_y=True)
+    est.fit(ds.data, ds.target)
+    with pytest.raises(NotFittedError, match="fitted with a dataframe"):
+        est.kneighbors(return_dataframe_index=True)
+    est.fit(ds.data.tolist(), ds.target)
+    assert not hasattr(est, "dataframe_index_in_")
+    est.fit(X_df, ds.target)
+    np.testing.assert_array_equal(est.dataframe_index_in_, ds.index)
+    idx = est.kneighbors(X_df, return_distance=False, return_dataframe_index=True)
+    np.testing.assert_array_equal(idx.ravel(), ds.index)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_lists_dataframes_and_output_types(E, moscow, moscow_frames, name):
+    cls, kw = _estimators(E)[name]
+    est = cls(**kw).fit(moscow["X_train"].tolist(), moscow["y_train"].tolist())
+    p = est.predict(moscow["X_test"].tolist())
+    assert isinstance(p, np.ndarray) and p.shape == (33, 35)
+    est = cls(**kw).fit(moscow_frames["X_train"], moscow_frames["y_train"])
+    assert isinstance(est.predict(moscow_frames["X_test"]), np.ndarray)
+    with pytest.warns(UserWarning, match="fitted with feature names"):
+        est.predict(moscow["X_test"])
+    d, i = est.kneighbors(moscow_frames["X_test"])
+    assert d.dtype == np.float64 and i.dtype == np.int64 and d.shape == i.shape == (33, 5)
+
+
+@pytest.mark.parametrize("name", ["gnn", "msn"])
+def test_y_fit(E, moscow, name):
+    cls, kw = _estimators(E)[name]
+    X, y = moscow["X_train"], moscow["y_train"]
+    y_fit = y[:, :5]
+    est = cls(**kw).fit(X, y)
+    assert est.y_fit_ is None
+    without = est.independent_prediction_
+    est.fit(X, y, y_fit=y_fit)
+    np.testing.assert_array_equal(est.y_fit_, y_fit)
+    assert not np.array_equal(est.independent_prediction_, without)
+
+
+@pytest.mark.parametrize("name", ["euclidean", "gnn"])
+def test_gridsearch_and_pickle(E, moscow, name):
+    from sklearn.model_selection import GridSearchCV
+
+    cls, kw = _estimators(E)[name]
+    X, y = moscow["X_train"], moscow["y_train"]
+    gs = GridSearchCV(cls(**kw), param_grid={"n_neighbors": [1, 3]}, cv=2)
+    gs.fit(X, y)
+    gs.predict(X)
+    est = cls(**kw).fit(X, y)
+    clone = pickle.loads(pickle.dumps(est))
+    np.testing.assert_array_equal(clone.predict(moscow["X_test"]), est.predict(moscow["X_test"]))
+
+
+def test_transformed_feature_count(E, moscow):
+    for name in ("euclidean", "mahalanobis", "gnn", "msn"):
+        cls, kw = _estimators(E)[name]
+        est = cls(**kw).fit(moscow["X_train"], moscow["y_train"])
+        assert est.transformer_.n_features_in_ == 28
+        assert est.n_features_in_ == len(est.transformer_.get_feature_names_out())
+
+
+@pytest.mark.parametrize(("deterministic", "expected"), [(False, [1, 0]), (True, [0, 1])])
+def test_kneighbors_deterministic_ordering(E, deterministic, expected):
+    """REF tests/test_estimators.py:306-327."""
+    X = np.array([1e-11, 1e-12, 1.0]).reshape(-1, 1)
+    est = E.RawKNNRegressor(n_neighbors=2).fit(X, np.array([0, 1, 2]))
+    _, idx = est.kneighbors(np.array([[0.0]]), use_deterministic_ordering=deterministic)
+    assert idx[0].tolist() == expected
+
+
+def test_kneighbors_uses_index_difference(E):
+    """REF tests/test_estimators.py:330-348."""
+    X = np.array([1e-11, 1e-12, 1.0]).reshape(-1, 1)
+    est = E.RawKNNRegressor(n_neighbors=2).fit(X, np.array([0, 1, 2]))
+    _, idx = est.kneighbors(np.array([[0.0], [0.0]]))
+    assert idx.tolist() == [[0, 1], [1, 0]]
+
+
+@pytest.mark.parametrize(("decimals", "expected"), [(8, [2, 1, 0]), (5, [1, 2, 0]), (2, [0, 1, 2])])
+def test_kneighbors_precision_decimals(E, monkeypatch, decimals, expected):
+    """REF tests/test_estimators.py:351-378."""
+    monkeypatch.setattr(E.RawKNNRegressor, "DISTANCE_PRECISION_DECIMALS", decimals)
+    X = np.array([1e-3, 1e-6, 1e-9, 1.0]).reshape(-1, 1)
+    est = E.RawKNNRegressor(n_neighbors=3).fit(X, np.array([0, 1, 2, 3]))
+    _, idx = est.kneighbors(np.array([[0.0]]))
+    assert idx[0].tolist() == expected
+
+
+def test_k_too_large_is_a_value_error(E, moscow):
+    est = E.RawKNNRegressor(n_neighbors=3).fit(moscow["X_train"][:6], moscow["y_train"][:6])
+    with pytest.raises(ValueError, match="Expected n_neighbors <= n_samples_fit"):
+        est.kneighbors(moscow["X_test"], n_neighbors=7)
+    with pytest.raises(NotImplementedError, match="Euclidean"):
+        E.RawKNNRegressor(metric="manhattan").fit(moscow["X_train"], moscow["y_train"])

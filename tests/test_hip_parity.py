@@ -1,0 +1,334 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle
+on the same seeded inputs and against the committed golden vectors.
+
+Bars (BASELINE.json north_star): neighbour indices bit-exact; distances and predictions
+within 1e-5 relative of the reference.  Against the oracle the HIP path is in fact held to
+bit-equality of float64 distances (same fma chains), which the tests assert."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from conftest import assert_neighbors_match, load_golden, yaimpute_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    from sknnr_amd import _native
+
+    assert _native.device_count() >= 1, "no MI355X visible: the HIP path cannot be tested"
+    return _native
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+def _synth(n_ref, nq, d, **kw):
+    from sknnr_amd import synth
+
+    return synth.make_problem(n_ref, nq, d, t=kw.pop("t", 6), **kw)
+
+
+# ---------------------------------------------------------------------------------------------
+# the MFMA pre-filter itself: operand maps and error budget
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [3, 8, 16, 17, 32, 64, 100, 128])
+def test_coarse_error_budget(N, d):
+    """Every value of the split f16x3 contraction must be within the budget the certificate
+    assumes; a wrong fragment map would show up here as O(1) errors, not as slow fallbacks."""
+    x_ref, _, x_q = _synth(1500, 200, d, t=2)
+    ix = N.Index(x_ref)
+    m, qn, s, eps_c = ix.debug_coarse_matrix(x_q)
+    mu = x_ref.mean(axis=0)
+    rp, qp = s * (x_ref - mu), s * (x_q - mu)
+    exact = (rp * rp).sum(1)[None, :] - 2.0 * qp @ rp.T
+    np.testing.assert_allclose(qn, (qp * qp).sum(1), rtol=1e-12)
+    unit = (np.sqrt((qp * qp).sum(1))[:, None] + np.sqrt((rp * rp).sum(1))[None, :]) ** 2
+    ratio = np.abs(m - exact) / (eps_c * unit)
+    assert ratio.max() < 0.5, f"coarse error uses {ratio.max():.2f} of the budget"
+    ix.close()
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 1e3, 1e6])
+def test_coarse_is_scale_invariant(N, scale):
+    x_ref, _, x_q = _synth(600, 64, 24, t=2)
+    ix = N.Index(x_ref * scale + 7.0 * scale)
+    m, qn, s, eps_c = ix.debug_coarse_matrix(x_q * scale + 7.0 * scale)
+    mu = (x_ref * scale + 7.0 * scale).mean(axis=0)
+    rp, qp = s * (x_ref * scale + 7.0 * scale - mu), s * (x_q * scale + 7.0 * scale - mu)
+    exact = (rp * rp).sum(1)[None, :] - 2.0 * qp @ rp.T
+    unit = (np.sqrt((qp * qp).sum(1))[:, None] + np.sqrt((rp * rp).sum(1))[None, :]) ** 2
+    assert (np.abs(m - exact) / (eps_c * unit)).max() < 0.5
+    ix.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# kneighbors / predict against the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [2, 8, 16, 17, 32, 64, 100])
+@pytest.mark.parametrize("k", [1, 5, 7])
+def test_kneighbors_matches_oracle(N, O, d, k):
+    x_ref, y, x_q = _synth(2048, 1000, d)
+    ix = N.Index(x_ref, y)
+    for formula, fname in ((N.FORMULA_EXPANDED, "expanded"), (N.FORMULA_DIRECT, "direct")):
+        dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k, formula=formula))
+        od, oi = O.kneighbors(x_ref, x_q, k, fname)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)  # same fma chains -> bit-equal float64
+        dist, idx = ix.kneighbors_host(None, ix.make_opts(k, formula=formula, exclude_self=True), nq=2048)
+        od, oi = O.kneighbors(x_ref, None, k, fname)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+    st = ix.stats()
+    if k + 1 <= 7:
+        assert st["coarse_queries"] == st["queries"]
+        assert st["exact_fallbacks"] <= 0.01 * st["queries"], st
+    ix.close()
+
+
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_exact_ties_and_zero_distances(N, O, deterministic):
+    """Exact duplicate reference rows (distance ties) and queries that are copies of
+    reference rows (zero / cancellation-noise distances)."""
+    x_ref, y, x_q = _synth(2048, 1024, 32, n_dup_refs=96, n_dup_queries=64)
+    ix = N.Index(x_ref, y)
+    for k in (1, 5):
+        dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k, deterministic=deterministic))
+        od, oi = O.kneighbors(x_ref, x_q, k, "expanded", deterministic=deterministic)
+        np.testing.assert_array_equal(dist, od)
+        if deterministic:
+            np.testing.assert_array_equal(idx, oi)
+        else:  # the reference's quicksort order among exactly tied distances is not restated on the device
+            assert_neighbors_match(idx, dist, oi, od, fit_X=x_ref)
+        dist, idx = ix.kneighbors_host(None, ix.make_opts(k, exclude_self=True, deterministic=deterministic), nq=2048)
+        od, oi = O.kneighbors(x_ref, None, k, "expanded", deterministic=deterministic)
+        np.testing.assert_array_equal(dist, od)
+        if deterministic:
+            np.testing.assert_array_equal(idx, oi)
+    ix.close()
+
+
+@pytest.mark.parametrize("k", [9, 16, 40])
+def test_large_k_uses_the_exact_scan(N, O, k):
+    x_ref, y, x_q = _synth(700, 300, 20)
+    ix = N.Index(x_ref, y)
+    dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k))
+    od, oi = O.kneighbors(x_ref, x_q, k, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(dist, od)
+    dist, idx = ix.kneighbors_host(None, ix.make_opts(k, exclude_self=True), nq=700)
+    od, oi = O.kneighbors(x_ref, None, k, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    assert ix.stats()["exact_only_queries"] == 1000
+    ix.close()
+
+
+def test_wide_features_use_the_exact_scan(N, O):
+    x_ref, y, x_q = _synth(500, 200, 150)
+    ix = N.Index(x_ref, y)
+    dist, idx = ix.kneighbors_host(x_q, ix.make_opts(5))
+    od, oi = O.kneighbors(x_ref, x_q, 5, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(dist, od)
+    ix.close()
+
+
+def test_certificate_failures_fall_back_to_the_exact_scan(N, O):
+    """Force the rare branch: references packed so tightly (relative spread 1e-7) that the
+    f32-class pre-filter cannot separate them -> certificates fail -> float64 scan; results
+    must still be exact."""
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((1, 16)) * 100.0
+    x_ref = base + 1e-5 * rng.standard_normal((3000, 16))
+    x_ref[0] += 50.0  # one far row keeps the coarse scale large
+    x_q = base + 1e-5 * rng.standard_normal((512, 16))
+    ix = N.Index(x_ref)
+    dist, idx = ix.kneighbors_host(x_q, ix.make_opts(5))
+    od, oi = O.kneighbors(x_ref, x_q, 5, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(dist, od)
+    st = ix.stats()
+    assert st["exact_fallbacks"] > 0, "this input is meant to exercise the fallback"
+    ix.close()
+
+
+def test_overflowing_queries_are_still_exact(N, O):
+    """Queries far outside the f16 range of the coarse image (|q| >> 512 x the reference
+    spread) overflow to inf in the pre-filter and must be answered by the exact scan."""
+    x_ref, y, x_q = _synth(1000, 64, 8)
+    x_q[:8] *= 1e7
+    ix = N.Index(x_ref)
+    dist, idx = ix.kneighbors_host(x_q, ix.make_opts(3))
+    od, oi = O.kneighbors(x_ref, x_q, 3, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_allclose(dist, od, rtol=1e-12)
+    ix.close()
+
+
+@pytest.mark.parametrize("n_ref", [1, 2, 7, 31, 33, 257])
+def test_tiny_reference_sets(N, O, n_ref):
+    x_ref, y, x_q = _synth(n_ref, 70, 5)
+    ix = N.Index(x_ref, y)
+    for k in sorted({1, min(3, n_ref), n_ref if n_ref <= 7 else 5}):
+        dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k))
+        od, oi = O.kneighbors(x_ref, x_q, k, "expanded")
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+    ix.close()
+
+
+def test_errors_follow_the_reference(N):
+    x_ref, y, x_q = _synth(10, 4, 3)
+    ix = N.Index(x_ref, y)
+    with pytest.raises(N.HipBackendError, match="Expected n_neighbors <= n_samples_fit, but n_neighbors = 11"):
+        ix.kneighbors_host(x_q, ix.make_opts(11))
+    with pytest.raises(N.HipBackendError, match="Expected n_neighbors < n_samples_fit, but n_neighbors = 10"):
+        ix.kneighbors_host(None, ix.make_opts(10, exclude_self=True), nq=10)
+    with pytest.raises(N.HipBackendError, match="Expected n_neighbors > 0"):
+        ix.kneighbors_host(x_q, ix.make_opts(0))
+    dist, idx = ix.kneighbors_host(x_q[:0], ix.make_opts(2))
+    assert dist.shape == (0, 2) and idx.shape == (0, 2)
+    ix.close()
+
+
+@pytest.mark.parametrize("weights", ["uniform", "distance", yaimpute_weights])
+@pytest.mark.parametrize("k", [1, 5, 7, 12])
+def test_predict_matches_oracle(N, O, weights, k):
+    from sknnr_amd._engine import KNNEngine
+
+    x_ref, y, x_q = _synth(1500, 400, 16, t=9, n_dup_queries=16)
+    eng = KNNEngine(x_ref, y)
+    pred = eng.predict(x_q, k, weights)
+    od, oi = O.kneighbors(x_ref, x_q, k, "expanded")
+    np.testing.assert_allclose(pred, O.predict(y, od, oi, weights), rtol=1e-12, atol=0)
+    pred = eng.predict(None, k, weights, exclude_self=True)
+    od, oi = O.kneighbors(x_ref, None, k, "expanded")
+    np.testing.assert_allclose(pred, O.predict(y, od, oi, weights), rtol=1e-12, atol=0)
+    eng.close()
+
+
+def test_affine_transform_and_fused_query_transform(N, O):
+    from sknnr_amd import synth
+
+    x_ref, y, x_q = _synth(900, 300, 12)
+    rng = np.random.default_rng(3)
+    center, scale = rng.standard_normal(12), 0.5 + rng.random(12)
+    proj = rng.standard_normal((12, 20))
+    for c, s, p in ((center, scale, proj), (center, None, proj), (center, scale, None), (None, None, None)):
+        ref_t = N.affine_transform_host(x_ref, c, s, p)
+        np.testing.assert_array_equal(ref_t, O.affine(x_ref, c, s, p))
+        ix = N.Index(ref_t, y)
+        ix.set_affine(12, c, s, p)
+        dist, idx = ix.kneighbors_host(x_q, ix.make_opts(5, apply_affine=True))
+        od, oi = O.kneighbors(ref_t, O.affine(x_q, c, s, p), 5, "expanded")
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+        ix.close()
+
+
+def test_row_offset_and_chunk_independence(N, O):
+    """A call split into shards that carry their global row offset gives the same answer as
+    the whole call (the reorder's |idx - row| key)."""
+    x_ref = np.array([1e-11, 1e-12, 1.0]).reshape(-1, 1)
+    ix = N.Index(x_ref)
+    q = np.zeros((6, 1))
+    _, whole = ix.kneighbors_host(q, ix.make_opts(2))
+    parts = [ix.kneighbors_host(q[a:b], ix.make_opts(2, row_offset=a))[1] for a, b in ((0, 1), (1, 4), (4, 6))]
+    np.testing.assert_array_equal(np.vstack(parts), whole)
+    np.testing.assert_array_equal(whole, O.kneighbors(x_ref, q, 2, "expanded")[1])
+    assert whole[0].tolist() == [0, 1] and whole[1].tolist() == [1, 0]
+    ix.close()
+
+
+@pytest.mark.parametrize(("decimals", "expected"), [(8, [2, 1, 0]), (5, [1, 2, 0]), (2, [0, 1, 2])])
+def test_precision_decimals(N, decimals, expected):
+    x_ref = np.array([1e-3, 1e-6, 1e-9, 1.0]).reshape(-1, 1)
+    ix = N.Index(x_ref)
+    _, idx = ix.kneighbors_host(np.array([[0.0]]), ix.make_opts(3, decimals=decimals))
+    assert idx[0].tolist() == expected
+    ix.close()
+
+
+def test_torch_device_tensors_round_trip(N, O):
+    import torch
+
+    from sknnr_amd._engine import KNNEngine
+
+    x_ref, y, x_q = _synth(3000, 5000, 32, t=4)
+    eng = KNNEngine(x_ref, y)
+    xq = torch.as_tensor(x_q, device="cuda")
+    dist, idx = eng.kneighbors(xq, 5)
+    assert dist.is_cuda and idx.is_cuda and idx.dtype == torch.int64
+    od, oi = O.kneighbors(x_ref, x_q, 5, "expanded")
+    np.testing.assert_array_equal(idx.cpu().numpy(), oi)
+    np.testing.assert_array_equal(dist.cpu().numpy(), od)
+    pred = eng.predict(xq, 5, "distance")
+    np.testing.assert_allclose(pred.cpu().numpy(), O.predict(y, od, oi, "distance"), rtol=1e-12, atol=0)
+    ids = eng.crosswalk(idx, np.arange(3000, dtype=np.int64) + 100000)
+    np.testing.assert_array_equal(ids.cpu().numpy(), oi + 100000)
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors from the reference, through the C ABI
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [8, 16, 32, 64])
+@pytest.mark.parametrize("dup", [False, True])
+def test_reference_goldens_synthetic(N, d, dup):
+    from oracle import oracle as O
+
+    g = load_golden(f"synth_raw_d{d}{'_dup' if dup else ''}.npz")
+    x_ref, y, x_q = _synth(2048, 1024, d, n_dup_refs=96 if dup else 0, n_dup_queries=64 if dup else 0)
+    ix = N.Index(x_ref, y)
+    for k in (1, 5, 7):
+        formula = N.FORMULA_EXPANDED if O.fit_method(2048, d, k) == "brute" else N.FORMULA_DIRECT
+        dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k, formula=formula))
+        assert_neighbors_match(idx, dist, g[f"tgt_k{k}_nn"], g[f"tgt_k{k}_dist"], fit_X=x_ref, atol=2e-6)
+        dist, idx = ix.kneighbors_host(None, ix.make_opts(k, formula=formula, exclude_self=True), nq=2048)
+        assert_neighbors_match(idx, dist, g[f"ref_k{k}_nn"], g[f"ref_k{k}_dist"], fit_X=x_ref, atol=2e-6)
+        if not dup:
+            pred = ix.predict_host(x_q, ix.make_opts(k, formula=formula, weight_mode=N.WEIGHTS_DISTANCE))
+            np.testing.assert_allclose(pred, g[f"pred_distance_k{k}"], rtol=1e-5, atol=1e-8)
+    ix.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE-size properties (no CPU reference at these sizes)
+# ---------------------------------------------------------------------------------------------
+def test_full_size_properties(N, O):
+    """1M x 10k x 16 (BASELINE config 2 shape): sortedness, self-consistency under row
+    permutation, and a seeded subsample checked against the oracle."""
+    import torch
+
+    from sknnr_amd import synth
+    from sknnr_amd._engine import KNNEngine
+
+    n_ref, nq, d, k = 10000, 1 << 20, 16, 5
+    x_ref = synth.make_features(n_ref, d, seed=0)
+    eng = KNNEngine(x_ref)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    xq = torch.randn((nq, d), dtype=torch.float64, device="cuda", generator=g) @ torch.tensor(
+        synth.mixing_matrix(d), device="cuda")
+    dist, idx = eng.kneighbors(xq, k, deterministic=False)
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all()), "distances must ascend"
+    assert int(idx.min()) >= 0 and int(idx.max()) < n_ref
+    assert bool((idx.sort(dim=1).values[:, 1:] != idx.sort(dim=1).values[:, :-1]).all()), "neighbours are distinct"
+    # permutation invariance (without the position-dependent reorder)
+    perm = torch.randperm(nq, device="cuda", generator=g)
+    dist_p, idx_p = eng.kneighbors(xq[perm].contiguous(), k, deterministic=False)
+    assert torch.equal(idx_p, idx[perm]) and torch.equal(dist_p, dist[perm])
+    # subsample against the oracle
+    sub = torch.arange(0, nq, 257, device="cuda")
+    od, oi = O.kneighbors(x_ref, xq[sub].cpu().numpy(), k, "expanded", deterministic=False)
+    np.testing.assert_array_equal(idx[sub].cpu().numpy(), oi)
+    np.testing.assert_array_equal(dist[sub].cpu().numpy(), od)
+    st = eng.stats()
+    assert st["exact_fallbacks"] <= 1e-3 * st["queries"], st
+    eng.close()

@@ -1,0 +1,174 @@
+"""Host-side logic that needs no GPU: transformers against the reference's fitted matrices,
+engine selection rules, parameter validation, dataset loaders, and the rule that the product
+package never touches the oracle."""
+
+from __future__ import annotations
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+@pytest.mark.parametrize(
+    ("name", "factory"),
+    [
+        ("euclidean", lambda T: T.StandardScalerWithDOF(ddof=1)),
+        ("mahalanobis", lambda T: T.MahalanobisTransformer()),
+        ("gnn_full", lambda T: T.CCATransformer()),
+        ("gnn_reduced", lambda T: T.CCATransformer(3)),
+        ("msn_full", lambda T: T.CCorATransformer()),
+        ("msn_reduced", lambda T: T.CCorATransformer(3)),
+    ],
+)
+def test_transformers_reproduce_the_reference_fit(name, factory, moscow):
+    from sknnr_amd import transformers as T
+
+    g = load_golden(f"moscow_{name}.npz")
+    tr = factory(T).fit(moscow["X_train"], moscow["y_train"])
+    for attr in ("mean_", "scale_", "env_center_", "projector_", "transform_"):
+        if "tr_" + attr in g:
+            np.testing.assert_allclose(getattr(tr, attr), g["tr_" + attr], rtol=1e-8, atol=1e-10)
+    if "tr_scaler_mean_" in g:
+        np.testing.assert_allclose(tr.scaler_.mean_, g["tr_scaler_mean_"], rtol=1e-12)
+        np.testing.assert_allclose(tr.scaler_.scale_, g["tr_scaler_scale_"], rtol=1e-12)
+    if "tr_n_components_" in g:
+        assert tr.n_components_ == int(g["tr_n_components_"])
+    np.testing.assert_allclose(tr.transform(moscow["X_train"]), g["Xt_train"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(tr.transform(moscow["X_test"]), g["Xt_test"], rtol=1e-8, atol=1e-10)
+    # the affine triple handed to the device is the same map
+    c, s, p = tr.affine_params()
+    x = moscow["X_test"] - (0 if c is None else c)
+    x = x / (1 if s is None else s)
+    x = x if p is None else x @ p
+    np.testing.assert_allclose(x, g["Xt_test"], rtol=1e-8, atol=1e-10)
+
+
+def test_swo_and_synthetic_projectors(moscow):
+    from sknnr_amd import synth
+    from sknnr_amd import transformers as T
+    from sknnr_amd.datasets import load_swo_ecoplot
+
+    X, y = load_swo_ecoplot(return_X_y=True)
+    g = load_golden("swo_msn_k5.npz")
+    tr = T.CCorATransformer().fit(X, y)
+    assert tr.n_components_ == 17
+    np.testing.assert_allclose(tr.projector_, g["tr_projector_"], rtol=1e-7, atol=1e-10)
+    x_ref, y_pos, _ = synth.make_problem(1500, 8, 16, t=20, kind="positive")
+    g = load_golden("synth_est_gnn.npz")
+    tr = T.CCATransformer().fit(x_ref, y_pos)
+    np.testing.assert_allclose(tr.projector_, g["tr_projector_"], rtol=1e-7, atol=1e-10)
+    x_ref, y_lin, _ = synth.make_problem(1500, 8, 16, t=20, kind="linear")
+    g = load_golden("synth_est_msn.npz")
+    tr = T.CCorATransformer(8).fit(x_ref, y_lin)
+    np.testing.assert_allclose(tr.projector_, g["tr_projector_"], rtol=1e-7, atol=1e-10)
+
+
+def test_transformer_api_behaviour(moscow):
+    """REF tests/test_transformers.py:116-213."""
+    from sknnr_amd import transformers as T
+
+    X, y = moscow["X_train"], moscow["y_train"]
+    cca = T.CCATransformer(n_components=5).fit(X, y)
+    assert cca.get_feature_names_out().tolist() == [f"cca{i}" for i in range(5)]
+    assert cca.transform(X).shape == (132, 5)
+    cc = T.CCorATransformer(n_components=0).fit(X, y)
+    assert cc.transform(X).shape == (132, 0)
+    assert T.CCorATransformer().fit(X, y).get_feature_names_out()[0] == "ccora0"
+    with pytest.raises(ValueError, match=r"n_components=500 must be between 0 and \d+"):
+        T.CCATransformer(n_components=500).fit(X, y)
+    with pytest.raises(ValueError, match="`y` must be a 2D array"):
+        T.CCATransformer().fit(X, y[:, 0])
+    bad = y.copy()
+    bad[3] = 0.0
+    with pytest.raises(ValueError, match="All row sums must be greater than 0"):
+        T.CCATransformer().fit(X, bad)
+    m = T.MahalanobisTransformer().fit(X)
+    cov = np.cov(m.transform(X), rowvar=False)
+    np.testing.assert_allclose(cov, np.eye(28), atol=1e-8)
+    sc = T.StandardScalerWithDOF(ddof=1).fit(X)
+    np.testing.assert_allclose(sc.scale_, X.std(axis=0, ddof=1))
+
+
+def test_engine_selection_rule():
+    """SKL/neighbors/_base.py:620-648."""
+    from sknnr_amd._base import _resolve_fit_method
+
+    assert _resolve_fit_method("auto", 132, 28, 5) == "brute"
+    assert _resolve_fit_method("auto", 132, 6, 5) == "kd_tree"
+    assert _resolve_fit_method("auto", 132, 15, 5) == "kd_tree"
+    assert _resolve_fit_method("auto", 132, 16, 5) == "brute"
+    assert _resolve_fit_method("auto", 10, 3, 5) == "brute"  # k >= n // 2
+    assert _resolve_fit_method("brute", 1000, 3, 5) == "brute"
+    assert _resolve_fit_method("kd_tree", 1000, 30, 5) == "kd_tree"
+    with pytest.raises(ValueError):
+        _resolve_fit_method("nope", 10, 3, 1)
+
+
+def test_parameter_surface_matches_the_reference():
+    import sknnr_amd as E
+
+    raw = E.RawKNNRegressor().get_params()
+    assert raw == {"algorithm": "auto", "leaf_size": 30, "metric": "minkowski", "metric_params": None,
+                   "n_jobs": None, "n_neighbors": 5, "p": 2, "weights": "uniform"}
+    assert E.RawKNNRegressor.DISTANCE_PRECISION_DECIMALS == 10
+    assert set(E.GNNRegressor().get_params()) == set(raw) | {"n_components"}
+    assert set(E.MSNRegressor(n_components=3).get_params()) == set(raw) | {"n_components"}
+    assert set(E.EuclideanKNNRegressor().get_params()) == set(raw)
+    assert E.__all__ == ["RawKNNRegressor", "EuclideanKNNRegressor", "MahalanobisKNNRegressor",
+                         "MSNRegressor", "GNNRegressor"]
+
+
+def test_non_euclidean_metrics_raise():
+    from sknnr_amd._base import _effective_metric
+
+    assert _effective_metric("minkowski", 2, None) == "euclidean"
+    assert _effective_metric("euclidean", 2, None) == "euclidean"
+    for bad in (("minkowski", 1, None), ("manhattan", 2, None), (lambda a, b: 0.0, 2, None),
+                ("minkowski", 2, {"w": [1.0]})):
+        with pytest.raises(NotImplementedError):
+            _effective_metric(*bad)
+
+
+def test_datasets():
+    """REF tests/test_datasets.py:21-28 shapes."""
+    from sknnr_amd.datasets import load_moscow_stjoes, load_swo_ecoplot
+
+    m = load_moscow_stjoes()
+    assert m.data.shape == (165, 28) and m.target.shape == (165, 35) and m.index.dtype == np.int64
+    s = load_swo_ecoplot()
+    assert s.data.shape == (3005, 18) and s.target.shape == (3005, 25)
+    X, y = load_swo_ecoplot(return_X_y=True, as_frame=True)
+    assert list(X.index[:3]) == list(s.index[:3]) and X.shape == (3005, 18)
+    assert repr(m) == "Dataset(n=165, features=28, targets=35)"
+
+
+def test_product_never_touches_the_oracle_or_a_cpu_engine():
+    """The oracle is test infrastructure; the product path must not import it, nor
+    scikit-learn's neighbour engines."""
+    pkg = os.path.join(ROOT, "sknnr_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            text = open(os.path.join(dirpath, f)).read()
+            if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "knn_oracle" in text:
+                offenders.append((f, "oracle"))
+            if re.search(r"sklearn\.neighbors|KNeighborsRegressor\s*\(|pairwise_distances|cdist\(", text):
+                if f not in ("_base.py",) or re.search(r"^\s*(from|import)\s+sklearn\.neighbors", text, flags=re.M):
+                    offenders.append((f, "cpu engine"))
+    assert not offenders, offenders
+
+
+def test_synthetic_generators_are_deterministic():
+    from sknnr_amd import synth
+
+    a = synth.make_features(100, 8, seed=1)
+    b = synth.make_features(100, 8, seed=1)
+    np.testing.assert_array_equal(a, b)
+    x, y, q = synth.make_problem(200, 50, 8, t=5, kind="positive", n_dup_refs=10, n_dup_queries=5)
+    assert (y > 0).all() and np.array_equal(x[-10:], x[:10]) and np.array_equal(q[0], x[0])
