@@ -245,7 +245,23 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const double nrm = sqrt(qn) + a.ymax;
     const double eps = a.eps_c * nrm * nrm;
     const double bound = (qn + t_min - eps) * a.inv_s2;
-    const bool certified = (n_usable >= s.kk) && (tau < INFINITY) && (bound > tau);
+    bool certified = (n_usable >= s.kk) && (tau < INFINITY) && (bound > tau);
+    // Exactly tied float64 distances: which tied row the reference keeps at the k-th slot (and,
+    // without deterministic ordering, in which order it lists tied rows) depends on its heap's
+    // history -- such queries are replayed by exact_scan_kernel.
+    {
+        const bool mine = usable && (rank < s.kk);
+        int ties = 0;
+#pragma unroll
+        for (int j = 0; j < LPQ; ++j) {
+            const double dj = __shfl(d2, j, LPQ);
+            const int rj = __shfl(rank, j, LPQ);
+            if (s.deterministic) ties += (dj == d2) && mine && (rj >= s.kk);          // tie across the boundary
+            else ties += (dj == d2) && mine && (rj != rank);                            // any tie involving a kept row
+        }
+        const int any_tie = group_min_i<LPQ>(-ties);
+        if (any_tie < 0) certified = false;
+    }
 
     // X=None: drop the row's own index, or the first entry when it is absent
     // (SKL/neighbors/_base.py:936-963)
@@ -290,124 +306,222 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// exact_scan_kernel: one workgroup per query, every reference in float64.  Used for the
-// queries whose certificate failed and for calls outside the MFMA envelope (large k,
-// very wide features).  Per-thread sorted lists in LDS ([slot][thread], conflict-free),
-// then KK rounds of a workgroup-wide lexicographic arg-min.
+// exact_scan_kernel: the reference's engine itself, one wavefront per query.
+//
+// Every reference row is visited in ascending index order, its float64 distance pushed
+// into a fixed-size max-heap that rejects values equal to its root, the heap is sorted with
+// the reference's own (unstable) dual quicksort, then the X=None / sqrt / reorder post-steps
+// run -- a faithful replay of
+//   heap_push          SKL/utils/_heap.pyx:6-85
+//   simultaneous_sort  SKL/utils/_sorting.pyx:19-93
+//   drop self          SKL/neighbors/_base.py:936-963
+// so that even exactly tied distances (duplicate rows, integer-valued features,
+// cancellation-quantised clusters) come out as the reference returns them: which of several
+// tied rows survives at the k-th slot depends on the heap's history, not on the index.
+//
+// Used for (a) queries whose MFMA certificate failed, (b) queries with an exact tie at the
+// k-th slot (or, without deterministic ordering, any tie among the k), (c) calls outside the
+// MFMA envelope (large k, very wide features).  64 references per step: each lane evaluates
+// one distance from the transposed float64 copy of the references (coalesced), a ballot
+// against the heap's root finds the (rare) lanes to push, lane 0 replays those pushes in
+// index order on the heap in LDS.
 // ---------------------------------------------------------------------------------------
 struct ScanArgs {
-    SelectArgs s;
-    const int* list;   // query ids to process, or null = all 0..count-1
-    const int* count;  // device count (with list), else null and s.nq is used
+    SelectArgs s;       // s.ref is unused here; refT below
+    const double* refT; // (d, n_ref) transposed reference rows
+    const int* list;    // query ids to process, or null = all 0..count-1
+    const int* count;   // device count (with list), else null and s.nq is used
 };
 
-__global__ void exact_scan_kernel(ScanArgs a) {
+__device__ __forceinline__ void heap_push_ref(double* hv, int* hi, int k, double v, int id) {
+    // caller has checked v < hv[0]
+    int cur = 0;
+    for (;;) {
+        const int l = 2 * cur + 1, r = l + 1;
+        int nxt;
+        if (l >= k) break;
+        if (r >= k) {
+            if (hv[l] > v) nxt = l; else break;
+        } else if (hv[l] >= hv[r]) {
+            if (v < hv[l]) nxt = l; else break;
+        } else {
+            if (v < hv[r]) nxt = r; else break;
+        }
+        hv[cur] = hv[nxt];
+        hi[cur] = hi[nxt];
+        cur = nxt;
+    }
+    hv[cur] = v;
+    hi[cur] = id;
+}
+
+__device__ __forceinline__ void swap_slots(double* v, int* x, int a, int b) {
+    const double tv = v[a]; v[a] = v[b]; v[b] = tv;
+    const int tx = x[a]; x[a] = x[b]; x[b] = tx;
+}
+
+// The reference's recursive dual quicksort, run with an explicit stack (the two halves are
+// independent, so the visiting order does not change the result).
+__device__ void dual_quicksort_ref(double* v0, int* x0, int n0, int* stack) {
+    int sp = 0;
+    stack[sp++] = 0;
+    stack[sp++] = n0;
+    while (sp > 0) {
+        const int n = stack[--sp];
+        const int off = stack[--sp];
+        double* v = v0 + off;
+        int* x = x0 + off;
+        if (n <= 1) continue;
+        if (n == 2) {
+            if (v[0] > v[1]) swap_slots(v, x, 0, 1);
+            continue;
+        }
+        if (n == 3) {
+            if (v[0] > v[1]) swap_slots(v, x, 0, 1);
+            if (v[1] > v[2]) {
+                swap_slots(v, x, 1, 2);
+                if (v[0] > v[1]) swap_slots(v, x, 0, 1);
+            }
+            continue;
+        }
+        const int mid = n / 2;
+        if (v[0] > v[n - 1]) swap_slots(v, x, 0, n - 1);
+        if (v[n - 1] > v[mid]) {
+            swap_slots(v, x, n - 1, mid);
+            if (v[0] > v[n - 1]) swap_slots(v, x, 0, n - 1);
+        }
+        const double pivot = v[n - 1];
+        int store = 0;
+        for (int i = 0; i < n - 1; ++i) {
+            if (v[i] < pivot) {
+                swap_slots(v, x, i, store);
+                ++store;
+            }
+        }
+        swap_slots(v, x, store, n - 1);
+        if (store > 1) { stack[sp++] = off; stack[sp++] = store; }
+        if (store + 2 < n) { stack[sp++] = off + store + 1; stack[sp++] = n - store - 1; }
+    }
+}
+
+// Per-wave LDS slice: xs[d] | hv[KK] | hi[KK] | stack[2*KK+4]
+__host__ __device__ inline size_t scan_wave_bytes(int d, int kk) {
+    size_t b = 8 * (size_t)((d + 1) & ~1) + 8 * (size_t)kk + 4 * (size_t)(kk + (kk & 1));
+    b += 4 * (size_t)((2 * kk + 4 + 1) & ~1);
+    return (b + 15) & ~(size_t)15;
+}
+
+constexpr int kScanWaves = 4;
+
+__global__ void __launch_bounds__(kScanWaves * 64) exact_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const SelectArgs& s = a.s;
-    const int T = blockDim.x, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int KK = s.kk;
-    double* xs = (double*)smem_raw;               // d
-    double* lv = xs + ((s.d + 1) & ~1);           // [KK][T]
-    int* li = (int*)(lv + (size_t)KK * T);        // [KK][T]
-    double* rv = (double*)(li + (size_t)KK * T + ((KK * T) & 1));  // [KK] merged values
-    int* ri = (int*)(rv + KK);                    // [KK] merged ids
-    double* wv = (double*)(ri + KK + (KK & 1));   // [T/64] per-wave winners
-    int* wi = (int*)(wv + 4);                     // [T/64]
-    int* wo = wi + 4;                             // [T/64]
-    volatile int* win_owner_p = wo + 4;           // winner of the current round
+    char* mine = smem_raw + (size_t)wave * scan_wave_bytes(s.d, KK);
+    double* xs = (double*)mine;
+    double* hv = xs + ((s.d + 1) & ~1);
+    int* hi = (int*)(hv + KK);
+    int* stack = hi + KK + (KK & 1);
 
     const long n_items = a.list ? (long)*a.count : s.nq;
-    for (long f = blockIdx.x; f < n_items; f += gridDim.x) {
+    const long wave_id = (long)blockIdx.x * kScanWaves + wave;
+    const long n_waves = (long)gridDim.x * kScanWaves;
+    for (long f = wave_id; f < n_items; f += n_waves) {
         const long q = a.list ? (long)a.list[f] : f;
-        for (int c = tid; c < s.d; c += T) xs[c] = s.xq[q * s.d + c];
-        for (int i = 0; i < KK; ++i) {
-            lv[(size_t)i * T + tid] = INFINITY;
-            li[(size_t)i * T + tid] = 0x7fffffff;
+        for (int c = lane; c < s.d; c += 64) xs[c] = s.xq[q * s.d + c];
+        for (int i = lane; i < KK; i += 64) {
+            hv[i] = DBL_MAX;
+            hi[i] = 0;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        double qn = 0.0;
+        if (s.formula == 0)
+            for (int c = 0; c < s.d; ++c) qn = fma(xs[c], xs[c], qn);
+        double root = DBL_MAX;
 
-        for (int j = tid; j < s.n_ref; j += T) {
-            const double d2 = pair_d2(xs, s.ref + (long)j * s.d, s.d, s.rn[j], s.formula);
-            if (d2 < lv[(size_t)(KK - 1) * T + tid]) {
-                int i = KK - 1;
-                while (i > 0 && lv[(size_t)(i - 1) * T + tid] > d2) {
-                    lv[(size_t)i * T + tid] = lv[(size_t)(i - 1) * T + tid];
-                    li[(size_t)i * T + tid] = li[(size_t)(i - 1) * T + tid];
-                    --i;
+        for (int j0 = 0; j0 < s.n_ref; j0 += 64) {
+            const int j = j0 + lane;
+            double d2 = INFINITY;
+            if (j < s.n_ref) {
+                if (s.formula == 0) {
+                    double dot = 0.0;
+                    for (int c = 0; c < s.d; ++c) dot = fma(xs[c], a.refT[(size_t)c * s.n_ref + j], dot);
+                    d2 = qn + (-2.0 * dot) + s.rn[j];
+                    d2 = d2 > 0.0 ? d2 : 0.0;
+                } else {
+                    double acc = 0.0;
+                    for (int c = 0; c < s.d; ++c) {
+                        const double t = xs[c] - a.refT[(size_t)c * s.n_ref + j];
+                        acc = acc + t * t;
+                    }
+                    d2 = acc;
                 }
-                lv[(size_t)i * T + tid] = d2;
-                li[(size_t)i * T + tid] = j;
+            }
+            unsigned long long m = __builtin_amdgcn_ballot_w64(d2 < root);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const double v = __shfl(d2, b, 64);
+                if (v < root) {  // the root may have dropped since the ballot
+                    if (lane == 0) heap_push_ref(hv, hi, KK, v, j0 + b);
+                    __builtin_amdgcn_wave_barrier();
+                    root = hv[0];
+                }
             }
         }
 
-        int head = 0;
-        for (int round = 0; round < KK; ++round) {
-            double v = head < KK ? lv[(size_t)head * T + tid] : INFINITY;
-            int id = head < KK ? li[(size_t)head * T + tid] : 0x7fffffff;
-            int owner = tid;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double v2 = __shfl_xor(v, o, 64);
-                const int id2 = __shfl_xor(id, o, 64);
-                const int ow2 = __shfl_xor(owner, o, 64);
-                if (v2 < v || (v2 == v && id2 < id)) { v = v2; id = id2; owner = ow2; }
-            }
-            if ((tid & 63) == 0) { wv[tid >> 6] = v; wi[tid >> 6] = id; wo[tid >> 6] = owner; }
-            __syncthreads();
-            if (tid == 0) {
-                double bv = wv[0]; int bi = wi[0], bo = wo[0];
-                for (int w = 1; w < (T >> 6); ++w)
-                    if (wv[w] < bv || (wv[w] == bv && wi[w] < bi)) { bv = wv[w]; bi = wi[w]; bo = wo[w]; }
-                rv[round] = bv; ri[round] = bi; *win_owner_p = bo;
-            }
-            __syncthreads();
-            if (tid == *win_owner_p) ++head;
-        }
-
-        if (tid == 0) {
+        if (lane == 0) {
+            dual_quicksort_ref(hv, hi, KK, stack);
             // drop self (X=None), sqrt, reorder: serial over <= KK entries
             const long self_id = s.row_offset + q;
             int drop = -1;
             if (s.exclude_self) {
                 drop = 0;
                 for (int i = 0; i < KK; ++i)
-                    if ((long)ri[i] == self_id) { drop = i; break; }
+                    if ((long)hi[i] == self_id) { drop = i; break; }
             }
             int n = 0;
             for (int i = 0; i < KK; ++i) {
                 if (i == drop) continue;
-                rv[n] = sqrt(rv[i] > 0.0 ? rv[i] : 0.0);
-                ri[n] = ri[i];
+                hv[n] = sqrt(hv[i] > 0.0 ? hv[i] : 0.0);
+                hi[n] = hi[i];
                 ++n;
             }
             if (n > s.k) n = s.k;
             if (s.deterministic) {
                 double dmax = 0.0;
-                for (int i = 0; i < n; ++i) dmax = fmax(dmax, rv[i]);
+                for (int i = 0; i < n; ++i) dmax = fmax(dmax, hv[i]);
                 const double row_scale = fmax(dmax, 1.0);
-                // insertion sort by (rounded, |idx - row|, idx); lv/li of this thread's column are free now
+                // stable insertion sort by (rounded, |idx - row|, idx)  (REF _base.py:166-175)
                 for (int i = 1; i < n; ++i) {
-                    const double dv = rv[i]; const int iv = ri[i];
+                    const double dv = hv[i];
+                    const int iv = hi[i];
                     const double k0 = round_key(dv / row_scale, s.pow10, s.pow10_is_divisor);
-                    long k1 = (long)iv - self_id; k1 = k1 < 0 ? -k1 : k1;
+                    long k1 = (long)iv - self_id;
+                    k1 = k1 < 0 ? -k1 : k1;
                     int j = i - 1;
                     while (j >= 0) {
-                        const double k0j = round_key(rv[j] / row_scale, s.pow10, s.pow10_is_divisor);
-                        long k1j = (long)ri[j] - self_id; k1j = k1j < 0 ? -k1j : k1j;
-                        const bool greater = (k0j > k0) || (k0j == k0 && (k1j > k1 || (k1j == k1 && ri[j] > iv)));
+                        const double k0j = round_key(hv[j] / row_scale, s.pow10, s.pow10_is_divisor);
+                        long k1j = (long)hi[j] - self_id;
+                        k1j = k1j < 0 ? -k1j : k1j;
+                        const bool greater = (k0j > k0) || (k0j == k0 && (k1j > k1 || (k1j == k1 && hi[j] > iv)));
                         if (!greater) break;
-                        rv[j + 1] = rv[j]; ri[j + 1] = ri[j];
+                        hv[j + 1] = hv[j];
+                        hi[j + 1] = hi[j];
                         --j;
                     }
-                    rv[j + 1] = dv; ri[j + 1] = iv;
+                    hv[j + 1] = dv;
+                    hi[j + 1] = iv;
                 }
             }
             for (int i = 0; i < n; ++i) {
-                if (s.out_dist) s.out_dist[q * s.k + i] = rv[i];
-                s.out_idx[q * s.k + i] = ri[i];
+                if (s.out_dist) s.out_dist[q * s.k + i] = hv[i];
+                s.out_idx[q * s.k + i] = hi[i];
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -145,7 +145,7 @@ struct sknnr_index {
     DevBuf<double> center, scale, proj;  // proj padded to (d_in, 16*ks) when ks > 0 else (d_in, d)
     bool has_center = false, has_scale = false, has_proj = false;
 
-    DevBuf<double> ref64, rn64, y64, mu_dev;
+    DevBuf<double> ref64, refT, rn64, y64, mu_dev;  // refT: (d, n_ref) transposed copy for the exact scan
     DevBuf<char> rimg;
 
     // workspace (one chunk)
@@ -164,7 +164,7 @@ struct sknnr_index {
 
     ~sknnr_index() {
         (void)hipSetDevice(device);
-        for (auto* b : {&center, &scale, &proj, &ref64, &rn64, &y64, &mu_dev, &xt, &qnc, &xstage,
+        for (auto* b : {&center, &scale, &proj, &ref64, &refT, &rn64, &y64, &mu_dev, &xt, &qnc, &xstage,
                         &dist_stage, &pred_stage})
             b->release();
         rimg.release();
@@ -238,6 +238,13 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
     const size_t nd = (size_t)n_ref * d;
     HIP_TRY(ix->ref64.ensure(nd));
     HIP_TRY(hipMemcpy(ix->ref64.p, ref, nd * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<double> tr(nd);
+        for (int64_t i = 0; i < n_ref; ++i)
+            for (int c = 0; c < d; ++c) tr[(size_t)c * n_ref + i] = ref[(size_t)i * d + c];
+        HIP_TRY(ix->refT.ensure(nd));
+        HIP_TRY(hipMemcpy(ix->refT.p, tr.data(), nd * sizeof(double), hipMemcpyHostToDevice));
+    }
     HIP_TRY(ix->rn64.ensure(n_ref));
     row_norms_kernel<<<dim3((unsigned)((n_ref + 255) / 256)), dim3(256)>>>(ix->ref64.p, n_ref, d, ix->rn64.p);
     HIP_TRY(hipGetLastError());
@@ -552,27 +559,16 @@ int launch_coarse(sknnr_index* ix, long nq_pad, hipStream_t st) {
     return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for ks = %d", ix->ks);
 }
 
-size_t scan_lds_bytes(int d, int kk, int threads) {
-    size_t b = 8 * (size_t)((d + 1) & ~1);
-    b += 12 * (size_t)kk * threads + 4 * (((size_t)kk * threads) & 1);
-    b += 8 * (size_t)kk + 4 * (size_t)(kk + (kk & 1));
-    b += 32 + 16 + 16 + 16;
-    return b;
-}
-
-int launch_scan(const SelectArgs& s, const int* list, const int* count, long max_items, hipStream_t st) {
-    int threads = s.kk <= 32 ? 256 : (s.kk <= 64 ? 128 : 64);
-    size_t sh = scan_lds_bytes(s.d, s.kk, threads);
-    while (sh > 150 * 1024 && threads > 64) {
-        threads >>= 1;
-        sh = scan_lds_bytes(s.d, s.kk, threads);
-    }
+int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int* count, long max_items,
+                hipStream_t st) {
+    const size_t sh = kScanWaves * scan_wave_bytes(s.d, s.kk);
     if (sh > 150 * 1024)
         return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", s.k, s.d);
-    ScanArgs a{s, list, count};
+    ScanArgs a{s, ix->refT.p, list, count};
     HIP_TRY(hipFuncSetAttribute((const void*)exact_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    const long blocks = std::max<long>(1, std::min<long>(max_items, 256L * 8));
-    exact_scan_kernel<<<dim3((unsigned)blocks), dim3(threads), sh, st>>>(a);
+    // 16 waves per CU keep the float64 pipes busy; queries are dealt to waves round-robin
+    const long blocks = std::max<long>(1, std::min<long>((max_items + kScanWaves - 1) / kScanWaves, 256L * 4));
+    exact_scan_kernel<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
     HIP_TRY(hipGetLastError());
     return SKNNR_OK;
 }
@@ -691,7 +687,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             const long threads = n * 2 * kListLen;
             finalize_kernel<kListLen><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(f);
             HIP_TRY(hipGetLastError());
-            rc = launch_scan(s, ix->fail_list.p, ix->fail_count.p, n, st);
+            rc = launch_scan(ix, s, ix->fail_list.p, ix->fail_count.p, n, st);
             if (rc) return rc;
             // keep a running total on the device; sknnr_get_stats reads it (no sync here)
             add_counter_kernel<<<dim3(1), dim3(1), 0, st>>>(ix->fail_count.p, ix->fail_total.p);
@@ -708,7 +704,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
                 int rc = launch_prep(ix, xin, n, n_pad, true, ix->xt.p, st);
                 if (rc) return rc;
             }
-            int rc = launch_scan(s, nullptr, nullptr, n, st);
+            int rc = launch_scan(ix, s, nullptr, nullptr, n, st);
             if (rc) return rc;
             ix->stats.exact_only_queries += n;
         }

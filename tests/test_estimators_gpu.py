@@ -205,7 +205,7 @@ def test_lists_dataframes_and_output_types(E, moscow, moscow_frames, name):
 def test_y_fit(E, moscow, name):
     cls, kw = _estimators(E)[name]
     X, y = moscow["X_train"], moscow["y_train"]
-    y_fit = y[:, :5]
+    y_fit = y[:, :10] + 0.25  # strictly positive rows (CCA needs positive row sums)
     est = cls(**kw).fit(X, y)
     assert est.y_fit_ is None
     without = est.independent_prediction_

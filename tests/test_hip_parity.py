@@ -103,15 +103,36 @@ def test_exact_ties_and_zero_distances(N, O, deterministic):
         dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k, deterministic=deterministic))
         od, oi = O.kneighbors(x_ref, x_q, k, "expanded", deterministic=deterministic)
         np.testing.assert_array_equal(dist, od)
-        if deterministic:
-            np.testing.assert_array_equal(idx, oi)
-        else:  # the reference's quicksort order among exactly tied distances is not restated on the device
-            assert_neighbors_match(idx, dist, oi, od, fit_X=x_ref)
+        np.testing.assert_array_equal(idx, oi)  # tied rows too: the heap and quicksort are replayed
         dist, idx = ix.kneighbors_host(None, ix.make_opts(k, exclude_self=True, deterministic=deterministic), nq=2048)
         od, oi = O.kneighbors(x_ref, None, k, "expanded", deterministic=deterministic)
         np.testing.assert_array_equal(dist, od)
-        if deterministic:
-            np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(idx, oi)
+    ix.close()
+
+
+@pytest.mark.parametrize("deterministic", [True, False])
+@pytest.mark.parametrize("k", [1, 3, 6])
+def test_integer_features_many_exact_ties(N, O, deterministic, k):
+    """Integer-valued features make exact float64 distance ties the norm; which tied row the
+    reference keeps at the k-th slot depends on its heap's history, which the exact path
+    replays.  Also the X=None corner case with more duplicates than neighbours."""
+    rng = np.random.default_rng(7)
+    x_ref = rng.integers(0, 4, size=(1500, 6)).astype(np.float64)
+    x_q = rng.integers(0, 4, size=(400, 6)).astype(np.float64)
+    y = rng.standard_normal((1500, 3))
+    ix = N.Index(x_ref, y)
+    for formula, fname in ((N.FORMULA_EXPANDED, "expanded"),):
+        dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k, formula=formula, deterministic=deterministic))
+        od, oi = O.kneighbors(x_ref, x_q, k, fname, deterministic=deterministic)
+        np.testing.assert_array_equal(dist, od)
+        np.testing.assert_array_equal(idx, oi)
+        dist, idx = ix.kneighbors_host(None, ix.make_opts(k, formula=formula, exclude_self=True,
+                                                          deterministic=deterministic), nq=1500)
+        od, oi = O.kneighbors(x_ref, None, k, fname, deterministic=deterministic)
+        np.testing.assert_array_equal(dist, od)
+        np.testing.assert_array_equal(idx, oi)
+    assert ix.stats()["exact_fallbacks"] > 0
     ix.close()
 
 
