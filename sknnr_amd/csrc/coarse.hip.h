@@ -37,17 +37,37 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // C-operand init  [lane half][16] f32.
 __host__ __device__ constexpr int tile_frag_bytes(int ks) { return 2 * ks * 1024; }
 __host__ __device__ constexpr int tile_bytes(int ks) { return 2 * ks * 1024 + 128; }
-// 32-reference tiles per LDS stage (stage <= ~33 KiB so two stages fit beside anything).
-__host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 8 : (ks <= 4 ? 4 : 2); }
+// 32-reference tiles per LDS stage (stage <= ~17 KiB: two stages + the candidate queues stay
+// under 80 KiB so that two 8-wave workgroups share a CU = 4 waves per SIMD).
+__host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 4 : (ks <= 4 ? 2 : 1); }
 // Row of the 32x32 accumulator held in register r of a lane in half h (guide section 3).
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 constexpr int kCoarseWaves = 8;
 constexpr int kCoarseThreads = kCoarseWaves * 64;
 
-__device__ __forceinline__ float min3f(float a, float b, float c) {
-    return __builtin_fminf(a, __builtin_fminf(b, c));
+// v_min3_f32 / v_min_f32 as raw instructions: the compiler would put a canonicalising
+// v_max in front of every fminf operand that comes out of an MFMA (16 extra VALU per tile).
+// HAZARD (guide section 5.7 item 2): hipcc pads the MFMA -> VALU-read wait states only for
+// instructions it can see, not for the inside of an asm statement.  Every asm below that
+// reads accumulator registers therefore takes `dep`, a value produced by a compiler-visible
+// VALU instruction (first_min) that read the same MFMA result: the data dependence keeps the
+// asm behind that instruction, and the compiler pads that instruction correctly.
+__device__ __forceinline__ float first_min(float a, float b) {
+    return __builtin_amdgcn_fmed3f(a, b, -INFINITY);  // median(a, b, -inf) = min(a, b), one v_med3_f32
 }
+__device__ __forceinline__ float min3f(float a, float b, float c, float dep) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c), "v"(dep));
+    return r;
+}
+__device__ __forceinline__ float min2f(float a, float b, float dep) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b), "v"(dep));
+    return r;
+}
+// no accumulator operands: plain register values
+__device__ __forceinline__ float min2f(float a, float b) { return min2f(a, b, a); }
 
 // Sorted (ascending) insertion of (v, id) into a lane-local list whose last entry is
 // known to be > v.
@@ -69,19 +89,42 @@ __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], fl
     }
 }
 
-// The three-product split contraction of one 32-ref x 32-query tile.
+// Candidate queue of one lane: kQueueCap (value, index) pairs in LDS, laid out
+// [entry][lane] so that the batched flush reads conflict-free.  A hit is appended with a
+// handful of instructions; the 44-instruction sorted insertion runs later, for all lanes of
+// the wave at once (the flush), instead of once per hit with one or two lanes active.
+constexpr int kQueueCap = 4;
+constexpr int kQueueFlushAt = 2;
+__host__ __device__ constexpr int queue_bytes_per_wave(int nqb) { return nqb * kQueueCap * 64 * 8; }
+
+// The three-product split contraction of one 32-ref x 32-query tile, in two stages:
+//   main    = |r'|^2 + hi.hi                     (KS MFMAs)
+//   correct = main + lo.hi + hi.lo                (2 KS MFMAs)
+// |correct - main| <= 2^-9 |q'| |r'| (each lo is at most 2^-11 of its operand and the
+// reference operand carries the factor -2), so a tile whose `main` values all exceed the
+// lane thresholds by that margin cannot contain a hit and skips the correction MFMAs.
 template <int KS>
-__device__ __forceinline__ floatx16 split_contract(const half8 (&ah)[KS], const half8 (&al)[KS],
-                                                   const half8 (&bh)[KS], const half8 (&bl)[KS],
-                                                   floatx16 c0) {
+__device__ __forceinline__ floatx16 contract_main(const half8 (&ah)[KS], const half8 (&bh)[KS], floatx16 c0) {
     floatx16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh[0], c0, 0, 0, 0);
 #pragma unroll
     for (int s = 1; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acc, 0, 0, 0);
+    return acc;
+}
+template <int KS>
+__device__ __forceinline__ floatx16 contract_correct(const half8 (&ah)[KS], const half8 (&al)[KS],
+                                                     const half8 (&bh)[KS], const half8 (&bl)[KS],
+                                                     floatx16 acc) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], acc, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], acc, 0, 0, 0);
     return acc;
+}
+template <int KS>
+__device__ __forceinline__ floatx16 split_contract(const half8 (&ah)[KS], const half8 (&al)[KS],
+                                                   const half8 (&bh)[KS], const half8 (&bl)[KS],
+                                                   floatx16 c0) {
+    return contract_correct<KS>(ah, al, bh, bl, contract_main<KS>(ah, bh, c0));
 }
 
 // Copy `bytes` (multiple of 16) from global to LDS, lane-linear, by LDS-DMA.  Chunks of
@@ -99,14 +142,75 @@ __device__ __forceinline__ void stage_copy(const char* __restrict__ gsrc, char* 
     }
 }
 
+// The queue is accessed with inline-asm DS instructions: hipcc orders a compiler-visible
+// ds_write behind the stage's in-flight LDS-DMA (s_waitcnt vmcnt(0) before every append),
+// which would drain the prefetch on each hit.  The queue region is disjoint from the stage
+// buffers and DS operations of one wave execute in order, so no wait is needed on the write;
+// the read carries its own lgkmcnt(0) (guide section 5.7, form (i)).
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void queue_store(unsigned addr, float v, int id) {
+    const unsigned long long pr = ((unsigned long long)(unsigned)id << 32) | (unsigned long long)__float_as_uint(v);
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(pr) : "memory");
+}
+__device__ __forceinline__ unsigned long long queue_load(unsigned addr) {
+    unsigned long long pr;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pr) : "v"(addr) : "memory");
+    return pr;
+}
+
+// One hit: append to the lane's queue, or -- queue full -- insert directly.
+template <int M>
+__device__ __forceinline__ void take_hit(float v, int id, float (&vals)[M], int (&idxs)[M], float& thr,
+                                         int& cnt, unsigned qlane) {
+    const bool hit = v < thr;
+    if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
+    const bool room = cnt < kQueueCap;
+    if (hit && room) {
+        queue_store(qlane + cnt * 512, v, id);
+        cnt += 1;
+    }
+    if (__builtin_amdgcn_ballot_w64(hit && !room) != 0) {
+        if (hit && !room) {
+            list_insert<M>(vals, idxs, v, id);
+            thr = min2f(thr, vals[M - 1]);
+        }
+    }
+}
+
+// Batched insertion of every lane's queued candidates, then the threshold of the two lanes
+// that own the same query (l and l+32) is tightened to the smaller of their list maxima:
+// everything either lane rejects from now on is >= that value, which is what the
+// finaliser's certificate assumes (min over the two lists' last entries).
+template <int M>
+__device__ __forceinline__ void flush_queue(float (&vals)[M], int (&idxs)[M], float& thr, int& cnt,
+                                            unsigned qlane) {
+    for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0; ++i) {
+        if (i < cnt) {
+            const unsigned long long e = queue_load(qlane + i * 512);
+            const float ev = __uint_as_float((unsigned)e);
+            if (ev < vals[M - 1]) list_insert<M>(vals, idxs, ev, (int)(e >> 32));
+        }
+    }
+    cnt = 0;
+    const float own = vals[M - 1];
+    const float other = __shfl_xor(own, 32, 64);
+    thr = min2f(own, other);
+}
+
 // KS  : 16-wide K-steps per split part (padded feature count / 16)
 // M   : list length per lane
 // NQB : 32-query blocks per wave
-template <int KS, int M, int NQB>
-__global__ void __launch_bounds__(kCoarseThreads, 2)
+// WPS : waves per SIMD the register budget is sized for (4: two workgroups per CU)
+// ABLATE : timing experiments only (results invalid): 1 = no epilogue, 2 = no hit handling
+template <int KS, int M, int NQB, int WPS, int ABLATE = 0>
+__global__ void __launch_bounds__(kCoarseThreads, WPS)
 coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
               int n_stages,
               const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments
+              const double* __restrict__ qnc,  // [n_qblocks*32] |q'|^2 (0 for padding rows)
+              float skip_scale,                // 2^-9 * max|r'| * (1 + slack): margin = skip_scale * |q'|
               float* __restrict__ cand_val,    // [n_qblocks*32][2][M]
               int* __restrict__ cand_idx) {
     constexpr int TPS = tiles_per_stage(KS);
@@ -118,6 +222,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
     const int qb0 = (blockIdx.x * kCoarseWaves + wave) * NQB;
+    const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue_bytes_per_wave(NQB) + lane * 8);
 
     // Queries of this wave: B fragments, resident for the whole sweep.
     half8 bh[NQB][KS], bl[NQB][KS];
@@ -134,8 +239,14 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 
     float vals[NQB][M];
     int idxs[NQB][M];
+    float thr[NQB];
+    float margin[NQB];
+    int cnt[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
+        thr[qb] = FLT_MAX;
+        cnt[qb] = 0;
+        margin[qb] = skip_scale * (float)sqrt(qnc[(size_t)(qb0 + qb) * 32 + (lane & 31)]) + 1e-30f;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
             vals[qb][i] = FLT_MAX;
@@ -148,12 +259,12 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 
     for (int st = 0; st < n_stages; ++st) {
         char* cur = smem + (st & 1) * STAGE;
-        if (st + 1 < n_stages)
+        if ((ABLATE < 3) && st + 1 < n_stages)
             stage_copy(rimg + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane);
 
 #pragma unroll 1
         for (int t = 0; t < TPS; ++t) {
-            const char* tb = cur + t * TB;
+            const char* tb = (ABLATE == 4) ? smem : cur + t * TB;  // 4: loop-invariant reads, hoisted by the compiler
             half8 ah[KS], al[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -176,30 +287,55 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
-                const floatx16 acc = split_contract<KS>(ah, al, bh[qb], bl[qb], c0);
-                // lane-local minimum of the 16 new values: 8 v_min3 instead of 16 compares
-                float m0 = min3f(acc[0], acc[1], acc[2]);
-                float m1 = min3f(acc[3], acc[4], acc[5]);
-                float m2 = min3f(acc[6], acc[7], acc[8]);
-                float m3 = min3f(acc[9], acc[10], acc[11]);
-                float m4 = min3f(acc[12], acc[13], acc[14]);
-                m0 = min3f(m0, m1, acc[15]);
-                m2 = min3f(m2, m3, m4);
-                const float mn = __builtin_fminf(m0, m2);
-                if (__builtin_amdgcn_ballot_w64(mn < vals[qb][M - 1]) != 0) {
+                floatx16 acc = contract_main<KS>(ah, bh[qb], c0);
+                if constexpr (ABLATE == 0) {
+                    // can any of the 16 x 64 values still beat its lane's threshold after correction?
+                    const float t0 = first_min(acc[0], acc[1]);
+                    const float a0 = min2f(t0, acc[2], t0), a1 = min3f(acc[3], acc[4], acc[5], t0);
+                    const float a2 = min3f(acc[6], acc[7], acc[8], t0), a3 = min3f(acc[9], acc[10], acc[11], t0);
+                    const float a4 = min3f(acc[12], acc[13], acc[14], t0);
+                    const float m1 = min3f(min3f(a0, a1, a2, t0), a3, min2f(a4, acc[15], t0), t0);
+                    if (__builtin_amdgcn_ballot_w64(m1 < thr[qb] + margin[qb]) == 0) continue;
+                }
+                acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
+                if constexpr (ABLATE == 1 || ABLATE >= 3) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[r];
-                        if (v < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], v, id_base + acc_row(r, 0));
+                    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
+                    continue;
+                }
+                const unsigned qlane = qwave + qb * (kQueueCap * 512);
+                // 4 x 4 hierarchy of lane-local minima: 10 VALU for 16 values
+                float g[4];
+                const float u0 = first_min(acc[0], acc[1]);
+                g[0] = min3f(u0, acc[2], acc[3], u0);
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    g[k] = min2f(min3f(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], u0), acc[4 * k + 3], u0);
+                const float mn = min2f(min3f(g[0], g[1], g[2], u0), g[3]);
+                if constexpr (ABLATE == 2) {
+                    asm volatile("" ::"v"(mn));
+                    continue;
+                }
+                if (__builtin_amdgcn_ballot_w64(mn < thr[qb]) != 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (__builtin_amdgcn_ballot_w64(g[k] < thr[qb]) != 0) {
+#pragma unroll
+                            for (int r = 4 * k; r < 4 * k + 4; ++r)
+                                take_hit<M>(acc[r], id_base + acc_row(r, 0), vals[qb], idxs[qb], thr[qb], cnt[qb], qlane);
+                        }
                     }
+                    if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0)
+                        flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qlane);
                 }
             }
         }
-        __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
+        if (ABLATE < 3) __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
     }
 
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
+        flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qwave + qb * (kQueueCap * 512));
         const size_t q = (size_t)(qb0 + qb) * 32 + (lane & 31);
         const size_t base = (q * 2 + half) * M;
 #pragma unroll

@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
             a.qimg[((size_t)(qb * 2 + 1) * a.ks + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, lo);
         }
     }
-    if (live && a.qnc) a.qnc[q] = qn;
+    if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? qn : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -175,8 +175,9 @@ __device__ __forceinline__ double round_key(double x, double p10, int divisor) {
 // ---------------------------------------------------------------------------------------
 struct FinalizeArgs {
     SelectArgs s;
-    const float* cand_val;  // [nq][2][M]
+    const float* cand_val;  // [nq][2][m_list]
     const int* cand_idx;
+    int m_list;             // entries per lane list written by the coarse kernel (<= M)
     const double* qnc;      // (nq)
     double inv_s2;          // 1 / s^2
     double eps_c;           // certificate: eps = eps_c * (sqrt(qnc) + ymax)^2 (already * 2^-24)
@@ -217,8 +218,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const bool live = q < s.nq;
     if (!live) q = s.nq - 1;  // keep the lane for the shuffles; it writes nothing
 
-    const int id = a.cand_idx[q * LPQ + c];
-    const float cv = a.cand_val[q * LPQ + c];
+    const int list = c / M, slot = c % M;
+    const bool has_slot = slot < a.m_list;
+    const long cpos = (q * 2 + list) * a.m_list + (has_slot ? slot : 0);
+    const int id = has_slot ? a.cand_idx[cpos] : -1;
+    const float cv = has_slot ? a.cand_val[cpos] : INFINITY;
     const bool valid = id >= 0 && id < s.n_ref;
 
     double d2 = INFINITY;
@@ -239,7 +243,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 
     // certificate: every reference outside the lists has a float64 d2 above tau
     const double tau = group_min<LPQ>(rank >= s.kk - 1 ? d2 : INFINITY);
-    const float t_last = (c % M == M - 1) ? (valid ? cv : INFINITY) : INFINITY;
+    const float t_last = (slot == a.m_list - 1) ? (valid ? cv : INFINITY) : INFINITY;
     const double t_min = group_min<LPQ>((double)t_last);
     const double qn = a.qnc[q];
     const double nrm = sqrt(qn) + a.ymax;
@@ -445,17 +449,30 @@ __global__ void __launch_bounds__(kScanWaves * 64) exact_scan_kernel(ScanArgs a)
             const int j = j0 + lane;
             double d2 = INFINITY;
             if (j < s.n_ref) {
+                // 8 independent coalesced loads in flight per step of the (ordered) fma chain
+                const double* col = a.refT + j;
+                const size_t ld = (size_t)s.n_ref;
+                double acc = 0.0;
+                int c = 0;
+                for (; c + 8 <= s.d; c += 8) {
+                    double r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) r[u] = col[(size_t)(c + u) * ld];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (s.formula == 0) acc = fma(xs[c + u], r[u], acc);
+                        else { const double t = xs[c + u] - r[u]; acc = acc + t * t; }
+                    }
+                }
+                for (; c < s.d; ++c) {
+                    const double r = col[(size_t)c * ld];
+                    if (s.formula == 0) acc = fma(xs[c], r, acc);
+                    else { const double t = xs[c] - r; acc = acc + t * t; }
+                }
                 if (s.formula == 0) {
-                    double dot = 0.0;
-                    for (int c = 0; c < s.d; ++c) dot = fma(xs[c], a.refT[(size_t)c * s.n_ref + j], dot);
-                    d2 = qn + (-2.0 * dot) + s.rn[j];
+                    d2 = qn + (-2.0 * acc) + s.rn[j];
                     d2 = d2 > 0.0 ? d2 : 0.0;
                 } else {
-                    double acc = 0.0;
-                    for (int c = 0; c < s.d; ++c) {
-                        const double t = xs[c] - a.refT[(size_t)c * s.n_ref + j];
-                        acc = acc + t * t;
-                    }
                     d2 = acc;
                 }
             }

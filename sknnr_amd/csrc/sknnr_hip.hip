@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -531,32 +532,49 @@ int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool aff
     return SKNNR_OK;
 }
 
-template <int KS>
+template <int KS, int M>
 int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
     constexpr int NQB = (KS <= 4) ? 2 : 1;
+    constexpr int WPS = (KS <= 2) ? 4 : 2;
     constexpr int QPB = kCoarseWaves * NQB * 32;
     constexpr int TPS = tiles_per_stage(KS);
-    constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS);
-    auto kern = coarse_kernel<KS, kListLen, NQB>;
+    constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS) + (size_t)kCoarseWaves * queue_bytes_per_wave(NQB);
+    auto kern = coarse_kernel<KS, M, NQB, WPS>;
+    if constexpr (KS == 2 && M == 6) {  // timing experiments (SKNNR_COARSE_ABLATE=1|2): results are invalid
+        const char* ab = std::getenv("SKNNR_COARSE_ABLATE");
+        if (ab && ab[0] == '1') kern = coarse_kernel<KS, M, NQB, WPS, 1>;
+        if (ab && ab[0] == '2') kern = coarse_kernel<KS, M, NQB, WPS, 2>;
+        if (ab && ab[0] == '3') kern = coarse_kernel<KS, M, NQB, WPS, 3>;
+        if (ab && ab[0] == '4') kern = coarse_kernel<KS, M, NQB, WPS, 4>;
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(kCoarseThreads), sh, st>>>(
-        ix->rimg.p, ix->n_stages, ix->qimg.p, ix->cand_val.p, ix->cand_idx.p);
+        ix->rimg.p, ix->n_stages, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
+        ix->cand_val.p, ix->cand_idx.p);
     HIP_TRY(hipGetLastError());
     return SKNNR_OK;
 }
 
-int launch_coarse(sknnr_index* ix, long nq_pad, hipStream_t st) {
+// list length per lane for kk neighbours searched: one spare slot keeps the certificate cheap
+int coarse_list_len(int kk) { return kk <= 5 ? 6 : 8; }
+
+template <int M>
+int launch_coarse_m(sknnr_index* ix, long nq_pad, hipStream_t st) {
     switch (ix->ks) {
-        case 1: return launch_coarse_ks<1>(ix, nq_pad, st);
-        case 2: return launch_coarse_ks<2>(ix, nq_pad, st);
-        case 3: return launch_coarse_ks<3>(ix, nq_pad, st);
-        case 4: return launch_coarse_ks<4>(ix, nq_pad, st);
-        case 5: return launch_coarse_ks<5>(ix, nq_pad, st);
-        case 6: return launch_coarse_ks<6>(ix, nq_pad, st);
-        case 7: return launch_coarse_ks<7>(ix, nq_pad, st);
-        case 8: return launch_coarse_ks<8>(ix, nq_pad, st);
+        case 1: return launch_coarse_ks<1, M>(ix, nq_pad, st);
+        case 2: return launch_coarse_ks<2, M>(ix, nq_pad, st);
+        case 3: return launch_coarse_ks<3, M>(ix, nq_pad, st);
+        case 4: return launch_coarse_ks<4, M>(ix, nq_pad, st);
+        case 5: return launch_coarse_ks<5, M>(ix, nq_pad, st);
+        case 6: return launch_coarse_ks<6, M>(ix, nq_pad, st);
+        case 7: return launch_coarse_ks<7, M>(ix, nq_pad, st);
+        case 8: return launch_coarse_ks<8, M>(ix, nq_pad, st);
     }
     return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for ks = %d", ix->ks);
+}
+
+int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, hipStream_t st) {
+    return m_list == 6 ? launch_coarse_m<6>(ix, nq_pad, st) : launch_coarse_m<8>(ix, nq_pad, st);
 }
 
 int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int* count, long max_items,
@@ -670,15 +688,17 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             }
             auto& ev = ix->coarse_events[ix->coarse_events_used++];
             HIP_TRY(hipEventRecord(ev.first, st));
-            rc = launch_coarse(ix, n_pad, st);
+            rc = launch_coarse(ix, n_pad, coarse_list_len(kk), st);
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ev.second, st));
 
+            if (std::getenv("SKNNR_COARSE_ABLATE")) continue;  // timing experiment: pre-filter only
             FinalizeArgs f{};
             f.s = s;
             f.cand_val = ix->cand_val.p;
             f.cand_idx = ix->cand_idx.p;
             f.qnc = ix->qnc.p;
+            f.m_list = coarse_list_len(kk);
             f.inv_s2 = 1.0 / (ix->s * ix->s);
             f.eps_c = eps_units(ix->ks) * std::ldexp(1.0, -24);
             f.ymax = ix->ymax;
