@@ -189,12 +189,20 @@ def main():
         alg_flops = 2.0 * nq * args.refs * d_t  # 2 Nq Nref D_t per pass
         achieved_tf = alg_flops / (coarse_ms * 1e-3) / 1e12
         alg_bytes = nq * args.dims * 8 + args.refs * d_t * 8 + nq * k * 16
+        traffic, traffic_note = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_coarse_pmc.json")
+        if os.path.exists(pmc_file) and (args.refs, d_t, k) == (50_000, 32, 5):
+            # PMC counters cannot be collected inside this process; the committed rocprofv3 --pmc
+            # passes of this same command give HBM bytes per query row for the dominant kernel
+            # (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section), scaled to this step.
+            pmc = json.load(open(pmc_file))
+            traffic = pmc["hbm_bytes_per_query_row"] * nq
+            traffic_note = "profiles/r01_coarse_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE), bytes per step"
         roofline = {
-            "kernel": "sknnr::coarse_kernel<KS=%d,M=8,NQB=2> (f16x3 split MFMA pre-filter + lane-local top-8)" % ((d_t + 15) // 16),
+            "kernel": "sknnr::coarse_kernel<KS=%d,M=%d,NQB=2> (f16x3 split MFMA pre-filter, correction products skipped when no lane can hit; lane-local top-M)" % ((d_t + 15) // 16, 6 if k <= 5 else 8),
             "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved_tf / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-            "executed_over_algorithmic": 3.0,
-            "frac_executed": 3.0 * achieved_tf / PEAK_F16_MFMA_TFLOPS,
+            "frac": achieved_tf / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+            "executed_over_algorithmic_max": 3.0,
             "vs_f32_mfma_peak": achieved_tf / PEAK_F32_MFMA_TFLOPS,
             "kernel_ms_per_step": coarse_ms, "all_kernels_ms_per_step": kernel_ms,
             "hbm_algorithmic_GBs": alg_bytes / (kernel_ms * 1e-3) / 1e9,

@@ -259,7 +259,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 
     for (int st = 0; st < n_stages; ++st) {
         char* cur = smem + (st & 1) * STAGE;
-        if ((ABLATE < 3) && st + 1 < n_stages)
+        if ((ABLATE < 3 || ABLATE == 6) && st + 1 < n_stages)
             stage_copy(rimg + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane);
 
 #pragma unroll 1
@@ -288,7 +288,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
                 floatx16 acc = contract_main<KS>(ah, bh[qb], c0);
-                if constexpr (ABLATE == 0) {
+                if constexpr (ABLATE == 0 || ABLATE >= 5) {
                     // can any of the 16 x 64 values still beat its lane's threshold after correction?
                     const float t0 = first_min(acc[0], acc[1]);
                     const float a0 = min2f(t0, acc[2], t0), a1 = min3f(acc[3], acc[4], acc[5], t0);
@@ -298,7 +298,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                     if (__builtin_amdgcn_ballot_w64(m1 < thr[qb] + margin[qb]) == 0) continue;
                 }
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
-                if constexpr (ABLATE == 1 || ABLATE >= 3) {
+                if constexpr (ABLATE == 1 || ABLATE == 3 || ABLATE == 4) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
                     continue;
@@ -330,7 +330,8 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 }
             }
         }
-        if (ABLATE < 3) __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
+        if (ABLATE == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment: no workgroup barrier
+        else if (ABLATE < 3) __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
     }
 
 #pragma unroll

@@ -546,6 +546,8 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
         if (ab && ab[0] == '2') kern = coarse_kernel<KS, M, NQB, WPS, 2>;
         if (ab && ab[0] == '3') kern = coarse_kernel<KS, M, NQB, WPS, 3>;
         if (ab && ab[0] == '4') kern = coarse_kernel<KS, M, NQB, WPS, 4>;
+        if (ab && ab[0] == '5') kern = coarse_kernel<KS, M, NQB, WPS, 5>;
+        if (ab && ab[0] == '6') kern = coarse_kernel<KS, M, NQB, WPS, 6>;
     }
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(kCoarseThreads), sh, st>>>(
