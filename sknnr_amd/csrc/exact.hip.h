@@ -54,13 +54,19 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
     n_here = n_here < 0 ? 0 : (n_here > BT ? BT : n_here);
     const long n_el = n_here * a.d_in;
     const double* xsrc = a.x + q0 * a.d_in;
-    for (long e = tid; e < n_el; e += BT) {
-        const int r = (int)(e / a.d_in);
-        const int c = (int)(e - (long)r * a.d_in);
-        double v = xsrc[e];
-        if (a.center) v = v - a.center[c];
-        if (a.scale) v = v / a.scale[c];
-        xs[r * ldx + c] = v;
+    {
+        // coalesced walk over the block's contiguous rows; (row, col) advanced incrementally
+        int r = tid / a.d_in, c = tid - (tid / a.d_in) * a.d_in;
+        const int dr = BT / a.d_in, dc = BT - dr * a.d_in;
+        for (long e = tid; e < n_el; e += BT) {
+            double v = xsrc[e];
+            if (a.center) v = v - a.center[c];
+            if (a.scale) v = v / a.scale[c];
+            xs[r * ldx + c] = v;
+            r += dr;
+            c += dc;
+            if (c >= a.d_in) { c -= a.d_in; ++r; }
+        }
     }
     __syncthreads();
 
@@ -125,20 +131,39 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double pair_d2(const double* __restrict__ x, const double* __restrict__ r,
                                           int d, double rn, int formula) {
-    if (formula == 0) {
-        double qn = 0.0, dot = 0.0;
-        for (int c = 0; c < d; ++c) {
-            const double xv = x[c];
-            qn = fma(xv, xv, qn);
-            dot = fma(xv, r[c], dot);
+    double qn = 0.0, acc = 0.0;
+    int c = 0;
+    if ((d & 1) == 0) {  // rows start 16-byte aligned: two elements per load, same k order
+        const double2* x2 = (const double2*)x;
+        const double2* r2 = (const double2*)r;
+        for (; c < d; c += 2) {
+            const double2 xv = x2[c >> 1], rv = r2[c >> 1];
+            if (formula == 0) {
+                qn = fma(xv.x, xv.x, qn);
+                acc = fma(xv.x, rv.x, acc);
+                qn = fma(xv.y, xv.y, qn);
+                acc = fma(xv.y, rv.y, acc);
+            } else {
+                const double t0 = xv.x - rv.x;
+                acc = acc + t0 * t0;  // -ffp-contract=off keeps the two roundings
+                const double t1 = xv.y - rv.y;
+                acc = acc + t1 * t1;
+            }
         }
-        double d2 = qn + (-2.0 * dot) + rn;
-        return d2 > 0.0 ? d2 : 0.0;
     }
-    double acc = 0.0;
-    for (int c = 0; c < d; ++c) {
-        const double t = x[c] - r[c];
-        acc = acc + t * t;  // -ffp-contract=off keeps the two roundings
+    for (; c < d; ++c) {
+        const double xv = x[c];
+        if (formula == 0) {
+            qn = fma(xv, xv, qn);
+            acc = fma(xv, r[c], acc);
+        } else {
+            const double t = xv - r[c];
+            acc = acc + t * t;
+        }
+    }
+    if (formula == 0) {
+        const double d2 = qn + (-2.0 * acc) + rn;
+        return d2 > 0.0 ? d2 : 0.0;
     }
     return acc;
 }
@@ -182,7 +207,8 @@ struct FinalizeArgs {
     double inv_s2;          // 1 / s^2
     double eps_c;           // certificate: eps = eps_c * (sqrt(qnc) + ymax)^2 (already * 2^-24)
     double ymax;            // max |s (r - mu)|
-    int* fail_list;
+    int* fail_list;         // call-relative row ids of uncertified queries
+    int fail_base;          // call-relative id of this launch's row 0
     int* fail_count;
 };
 
@@ -225,9 +251,25 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const float cv = has_slot ? a.cand_val[cpos] : INFINITY;
     const bool valid = id >= 0 && id < s.n_ref;
 
+    // Only candidates whose pre-filter value is within 2 eps of the kk-th smallest one can be
+    // among the kk nearest (or tie with them); the others are strictly farther than kk
+    // candidates and are not gathered.
+    const double qn = a.qnc[q];
+    const double nrm = sqrt(qn) + a.ymax;
+    const double eps = a.eps_c * nrm * nrm;
+    const float cve = valid ? cv : INFINITY;
+    int rank_c = 0;
+#pragma unroll
+    for (int j = 0; j < LPQ; ++j) {
+        const float cj = __shfl(cve, j, LPQ);
+        rank_c += (cj < cve) || (cj == cve && j < c);
+    }
+    const double tau_c = group_min<LPQ>(rank_c >= s.kk - 1 ? (double)cve : INFINITY);
+    const bool need = valid && ((double)cv <= tau_c + 2.0 * eps);
+
     double d2 = INFINITY;
-    if (valid) d2 = pair_d2(s.xq + q * s.d, s.ref + (long)id * s.d, s.d, s.rn[id], s.formula);
-    const bool usable = valid && (d2 == d2) && d2 < INFINITY;
+    if (need) d2 = pair_d2(s.xq + q * s.d, s.ref + (long)id * s.d, s.d, s.rn[id], s.formula);
+    const bool usable = need && (d2 == d2) && d2 < INFINITY;
     if (!usable) d2 = INFINITY;
     const int key_id = usable ? id : (0x7fffff00 + c);  // unusable slots sort last, distinct
 
@@ -245,9 +287,6 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const double tau = group_min<LPQ>(rank >= s.kk - 1 ? d2 : INFINITY);
     const float t_last = (slot == a.m_list - 1) ? (valid ? cv : INFINITY) : INFINITY;
     const double t_min = group_min<LPQ>((double)t_last);
-    const double qn = a.qnc[q];
-    const double nrm = sqrt(qn) + a.ymax;
-    const double eps = a.eps_c * nrm * nrm;
     const double bound = (qn + t_min - eps) * a.inv_s2;
     bool certified = (n_usable >= s.kk) && (tau < INFINITY) && (bound > tau);
     // Exactly tied float64 distances: which tied row the reference keeps at the k-th slot (and,
@@ -305,7 +344,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     }
     if (live && c == 0 && !certified) {
         const int slot = atomicAdd(a.fail_count, 1);
-        a.fail_list[slot] = (int)q;
+        a.fail_list[slot] = a.fail_base + (int)q;
     }
 }
 
@@ -445,46 +484,62 @@ __global__ void __launch_bounds__(kScanWaves * 64) exact_scan_kernel(ScanArgs a)
             for (int c = 0; c < s.d; ++c) qn = fma(xs[c], xs[c], qn);
         double root = DBL_MAX;
 
-        for (int j0 = 0; j0 < s.n_ref; j0 += 64) {
-            const int j = j0 + lane;
-            double d2 = INFINITY;
-            if (j < s.n_ref) {
-                // 8 independent coalesced loads in flight per step of the (ordered) fma chain
-                const double* col = a.refT + j;
-                const size_t ld = (size_t)s.n_ref;
-                double acc = 0.0;
-                int c = 0;
-                for (; c + 8 <= s.d; c += 8) {
-                    double r[8];
+        // 256 references per step: every lane evaluates 4 distances (columns j0 + lane + 64u of the
+        // transposed copy, coalesced) with 32 independent loads in flight per 8 features, then the
+        // four 64-wide groups are offered to the heap in index order.
+        for (int j0 = 0; j0 < s.n_ref; j0 += 256) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            const size_t ld = (size_t)s.n_ref;
+            int c = 0;
+            for (; c + 8 <= s.d; c += 8) {
+                double r[4][8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) r[u] = col[(size_t)(c + u) * ld];
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + lane + 64 * u;
+                    const double* col = a.refT + (j < s.n_ref ? j : 0);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (s.formula == 0) acc = fma(xs[c + u], r[u], acc);
-                        else { const double t = xs[c + u] - r[u]; acc = acc + t * t; }
+                    for (int w = 0; w < 8; ++w) r[u][w] = col[(size_t)(c + w) * ld];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        if (s.formula == 0) acc[u] = fma(xs[c + w], r[u][w], acc[u]);
+                        else { const double t = xs[c + w] - r[u][w]; acc[u] = acc[u] + t * t; }
                     }
                 }
-                for (; c < s.d; ++c) {
-                    const double r = col[(size_t)c * ld];
-                    if (s.formula == 0) acc = fma(xs[c], r, acc);
-                    else { const double t = xs[c] - r; acc = acc + t * t; }
-                }
-                if (s.formula == 0) {
-                    d2 = qn + (-2.0 * acc) + s.rn[j];
-                    d2 = d2 > 0.0 ? d2 : 0.0;
-                } else {
-                    d2 = acc;
+            }
+            for (; c < s.d; ++c) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + lane + 64 * u;
+                    const double rv = a.refT[(size_t)c * ld + (j < s.n_ref ? j : 0)];
+                    if (s.formula == 0) acc[u] = fma(xs[c], rv, acc[u]);
+                    else { const double t = xs[c] - rv; acc[u] = acc[u] + t * t; }
                 }
             }
-            unsigned long long m = __builtin_amdgcn_ballot_w64(d2 < root);
-            while (m) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1;
-                const double v = __shfl(d2, b, 64);
-                if (v < root) {  // the root may have dropped since the ballot
-                    if (lane == 0) heap_push_ref(hv, hi, KK, v, j0 + b);
-                    __builtin_amdgcn_wave_barrier();
-                    root = hv[0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + lane + 64 * u;
+                double d2 = INFINITY;
+                if (j < s.n_ref) {
+                    if (s.formula == 0) {
+                        d2 = qn + (-2.0 * acc[u]) + s.rn[j];
+                        d2 = d2 > 0.0 ? d2 : 0.0;
+                    } else {
+                        d2 = acc[u];
+                    }
+                }
+                unsigned long long m = __builtin_amdgcn_ballot_w64(d2 < root);
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const double v = __shfl(d2, b, 64);
+                    if (v < root) {  // the root may have dropped since the ballot
+                        if (lane == 0) heap_push_ref(hv, hi, KK, v, j0 + 64 * u + b);
+                        __builtin_amdgcn_wave_barrier();
+                        root = hv[0];
+                    }
                 }
             }
         }

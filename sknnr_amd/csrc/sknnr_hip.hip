@@ -640,96 +640,104 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     const bool self_rows = xdev == nullptr;
     const bool coarse = ix->ks > 0 && kk <= kCoarseMaxKK;
     const int d_x = affine ? ix->d_in : ix->d;
+    if (nq > 0x7fffffffL) return fail(SKNNR_ERR_UNSUPPORTED, "more than 2^31 - 1 query rows in one call");
+    if (affine && ix->ks == 0)
+        return fail(SKNNR_ERR_UNSUPPORTED, "d = %d > 128 with an affine map is outside the HIP envelope", ix->d);
+
+    // transformed rows of the WHOLE call: the exact scan at the end reads any row of it
+    const double* xq_call = self_rows ? ix->ref64.p + o->row_offset * ix->d : xdev;
+    if (affine) {
+        HIP_TRY(ix->xt.ensure((size_t)nq * ix->d));
+        xq_call = ix->xt.p;
+    }
+    const long cap = std::min(kChunkRows, nq);
+    const long cap_pad = (cap + 511) / 512 * 512;
+    if (coarse || affine) {
+        HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
+        HIP_TRY(ix->qnc.ensure(cap_pad));
+    }
+    if (coarse) {
+        HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * kListLen));
+        HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * kListLen));
+        HIP_TRY(ix->fail_list.ensure(nq));
+        HIP_TRY(hipMemsetAsync(ix->fail_count.p, 0, 16, st));
+    }
+
+    SelectArgs call{};
+    call.xq = xq_call;
+    call.ref = ix->ref64.p;
+    call.rn = ix->rn64.p;
+    call.nq = nq;
+    call.d = ix->d;
+    call.n_ref = (int)ix->n_ref;
+    call.k = o->n_neighbors;
+    call.kk = kk;
+    call.exclude_self = o->exclude_self ? 1 : 0;
+    call.deterministic = o->deterministic ? 1 : 0;
+    call.formula = o->formula;
+    call.pow10_is_divisor = o->decimals < 0;
+    call.pow10 = std::pow(10.0, std::abs(o->decimals));
+    call.row_offset = o->row_offset;
+    call.out_dist = d_dist;
+    call.out_idx = d_idx;
 
     ix->coarse_events_used = 0;
     HIP_TRY(hipEventRecord(ix->ev_call0, st));
     for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
         const long n = std::min(kChunkRows, nq - c0);
         const long n_pad = (n + 511) / 512 * 512;
-        const double* xin = self_rows ? ix->ref64.p + (o->row_offset + c0) * ix->d : xdev + c0 * d_x;
-        const double* xq = xin;  // transformed rows the exact stages read
-        if (affine) {
-            HIP_TRY(ix->xt.ensure((size_t)std::min(kChunkRows, nq) * ix->d));
-            xq = ix->xt.p;
+        const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
+        if (coarse || affine) {
+            int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st);
+            if (rc) return rc;
         }
+        if (!coarse) continue;
 
-        SelectArgs s{};
-        s.xq = xq;
-        s.ref = ix->ref64.p;
-        s.rn = ix->rn64.p;
-        s.nq = n;
-        s.d = ix->d;
-        s.n_ref = (int)ix->n_ref;
-        s.k = o->n_neighbors;
-        s.kk = kk;
-        s.exclude_self = o->exclude_self ? 1 : 0;
-        s.deterministic = o->deterministic ? 1 : 0;
-        s.formula = o->formula;
-        s.pow10_is_divisor = o->decimals < 0;
-        s.pow10 = std::pow(10.0, std::abs(o->decimals));
-        s.row_offset = o->row_offset + c0;
-        s.out_dist = d_dist ? d_dist + c0 * o->n_neighbors : nullptr;
-        s.out_idx = d_idx + c0 * o->n_neighbors;
-
-        if (coarse) {
-            const long cap_pad = (std::min(kChunkRows, nq) + 511) / 512 * 512;
-            HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
-            HIP_TRY(ix->qnc.ensure(cap_pad));
-            HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * kListLen));
-            HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * kListLen));
-            HIP_TRY(ix->fail_list.ensure(cap_pad));
-            HIP_TRY(hipMemsetAsync(ix->fail_count.p, 0, 16, st));
-            int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p : nullptr, st);
-            if (rc) return rc;
-
-            if (ix->coarse_events_used == ix->coarse_events.size()) {
-                hipEvent_t e0, e1;
-                HIP_TRY(hipEventCreate(&e0));
-                HIP_TRY(hipEventCreate(&e1));
-                ix->coarse_events.emplace_back(e0, e1);
-            }
-            auto& ev = ix->coarse_events[ix->coarse_events_used++];
-            HIP_TRY(hipEventRecord(ev.first, st));
-            rc = launch_coarse(ix, n_pad, coarse_list_len(kk), st);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(ev.second, st));
-
-            if (std::getenv("SKNNR_COARSE_ABLATE")) continue;  // timing experiment: pre-filter only
-            FinalizeArgs f{};
-            f.s = s;
-            f.cand_val = ix->cand_val.p;
-            f.cand_idx = ix->cand_idx.p;
-            f.qnc = ix->qnc.p;
-            f.m_list = coarse_list_len(kk);
-            f.inv_s2 = 1.0 / (ix->s * ix->s);
-            f.eps_c = eps_units(ix->ks) * std::ldexp(1.0, -24);
-            f.ymax = ix->ymax;
-            f.fail_list = ix->fail_list.p;
-            f.fail_count = ix->fail_count.p;
-            const long threads = n * 2 * kListLen;
-            finalize_kernel<kListLen><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(f);
-            HIP_TRY(hipGetLastError());
-            rc = launch_scan(ix, s, ix->fail_list.p, ix->fail_count.p, n, st);
-            if (rc) return rc;
-            // keep a running total on the device; sknnr_get_stats reads it (no sync here)
-            add_counter_kernel<<<dim3(1), dim3(1), 0, st>>>(ix->fail_count.p, ix->fail_total.p);
-            HIP_TRY(hipGetLastError());
-            ix->stats.coarse_queries += n;
-        } else {
-            if (affine) {
-                // transform only: reuse the prep kernel when the coarse image exists, else fail loudly
-                if (ix->ks == 0)
-                    return fail(SKNNR_ERR_UNSUPPORTED, "d = %d > 128 with an affine map is outside the HIP envelope", ix->d);
-                const long cap_pad = (std::min(kChunkRows, nq) + 511) / 512 * 512;
-                HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
-                HIP_TRY(ix->qnc.ensure(cap_pad));
-                int rc = launch_prep(ix, xin, n, n_pad, true, ix->xt.p, st);
-                if (rc) return rc;
-            }
-            int rc = launch_scan(ix, s, nullptr, nullptr, n, st);
-            if (rc) return rc;
-            ix->stats.exact_only_queries += n;
+        if (ix->coarse_events_used == ix->coarse_events.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            ix->coarse_events.emplace_back(e0, e1);
         }
+        auto& ev = ix->coarse_events[ix->coarse_events_used++];
+        HIP_TRY(hipEventRecord(ev.first, st));
+        int rc = launch_coarse(ix, n_pad, coarse_list_len(kk), st);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev.second, st));
+
+        FinalizeArgs f{};
+        f.s = call;  // this chunk's window of the call
+        f.s.xq = xq_call + c0 * ix->d;
+        f.s.nq = n;
+        f.s.row_offset = o->row_offset + c0;
+        f.s.out_dist = d_dist ? d_dist + c0 * o->n_neighbors : nullptr;
+        f.s.out_idx = d_idx + c0 * o->n_neighbors;
+        f.cand_val = ix->cand_val.p;
+        f.cand_idx = ix->cand_idx.p;
+        f.qnc = ix->qnc.p;
+        f.m_list = coarse_list_len(kk);
+        f.inv_s2 = 1.0 / (ix->s * ix->s);
+        f.eps_c = eps_units(ix->ks) * std::ldexp(1.0, -24);
+        f.ymax = ix->ymax;
+        f.fail_list = ix->fail_list.p;
+        f.fail_count = ix->fail_count.p;
+        f.fail_base = (int)c0;
+        const long threads = n * 2 * kListLen;
+        finalize_kernel<kListLen><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(f);
+        HIP_TRY(hipGetLastError());
+    }
+    // One exact scan per call: the rows the finaliser could not certify (call-relative ids), or
+    // every row when the call is outside the MFMA envelope.
+    int rc = coarse ? launch_scan(ix, call, ix->fail_list.p, ix->fail_count.p, nq, st)
+                    : launch_scan(ix, call, nullptr, nullptr, nq, st);
+    if (rc) return rc;
+    if (coarse) {
+        // keep a running total on the device; sknnr_get_stats reads it (no sync here)
+        add_counter_kernel<<<dim3(1), dim3(1), 0, st>>>(ix->fail_count.p, ix->fail_total.p);
+        HIP_TRY(hipGetLastError());
+        ix->stats.coarse_queries += nq;
+    } else {
+        ix->stats.exact_only_queries += nq;
     }
     HIP_TRY(hipEventRecord(ix->ev_call1, st));
     ix->timing_pending = true;
