@@ -37,24 +37,25 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // C-operand init  [lane half][16] f32.
 __host__ __device__ constexpr int tile_frag_bytes(int ks) { return 2 * ks * 1024; }
 __host__ __device__ constexpr int tile_bytes(int ks) { return 2 * ks * 1024 + 128; }
-// 32-reference tiles per LDS stage (stage <= ~17 KiB: two stages + the candidate queues stay
-// under 80 KiB so that two 8-wave workgroups share a CU = 4 waves per SIMD).
-__host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 4 : (ks <= 4 ? 2 : 1); }
+// 32-reference tiles per LDS stage.  One 16-wave workgroup per CU (4 waves per SIMD) shares the
+// stage: two stage buffers + the waves' candidate queues must fit the 160 KiB of LDS.
+__host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 8 : (ks <= 4 ? 2 : 1); }
 // Row of the 32x32 accumulator held in register r of a lane in half h (guide section 3).
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-constexpr int kCoarseWaves = 8;
-constexpr int kCoarseThreads = kCoarseWaves * 64;
+// waves per workgroup: 16 (one 1024-thread workgroup per CU, 4 waves per SIMD at <= 128 VGPR) for
+// KS <= 2; 8 (2 waves per SIMD at <= 256 VGPR) for wider features
+__host__ __device__ constexpr int coarse_waves(int ks) { return ks <= 2 ? 16 : 8; }
 
 // v_min3_f32 / v_min_f32 as raw instructions: the compiler would put a canonicalising
 // v_max in front of every fminf operand that comes out of an MFMA (16 extra VALU per tile).
 // HAZARD (guide section 5.7 item 2): hipcc pads the MFMA -> VALU-read wait states only for
 // instructions it can see, not for the inside of an asm statement.  Every asm below that
 // reads accumulator registers therefore takes `dep`, a value produced by a compiler-visible
-// VALU instruction (first_min) that read the same MFMA result: the data dependence keeps the
+// VALU instruction (first_read) that read the same MFMA result: the data dependence keeps the
 // asm behind that instruction, and the compiler pads that instruction correctly.
-__device__ __forceinline__ float first_min(float a, float b) {
-    return __builtin_amdgcn_fmed3f(a, b, -INFINITY);  // median(a, b, -inf) = min(a, b), one v_med3_f32
+__device__ __forceinline__ float first_read(float a) {
+    return __builtin_canonicalizef(a);  // one compiler-visible v_max_f32 a, a: value unchanged
 }
 __device__ __forceinline__ float min3f(float a, float b, float c, float dep) {
     float r;
@@ -130,9 +131,9 @@ __device__ __forceinline__ floatx16 split_contract(const half8 (&ah)[KS], const 
 // Copy `bytes` (multiple of 16) from global to LDS, lane-linear, by LDS-DMA.  Chunks of
 // 1 KiB are dealt round-robin to the workgroup's waves.
 __device__ __forceinline__ void stage_copy(const char* __restrict__ gsrc, char* lds_dst, int bytes,
-                                           int wave, int lane) {
+                                           int wave, int lane, int n_waves) {
     const int n_chunks = (bytes + 1023) >> 10;
-    for (int c = wave; c < n_chunks; c += kCoarseWaves) {
+    for (int c = wave; c < n_chunks; c += n_waves) {
         const int off = (c << 10) + (lane << 4);
         if (off < bytes) {
             __builtin_amdgcn_global_load_lds(
@@ -203,9 +204,8 @@ __device__ __forceinline__ void flush_queue(float (&vals)[M], int (&idxs)[M], fl
 // M   : list length per lane
 // NQB : 32-query blocks per wave
 // WPS : waves per SIMD the register budget is sized for (4: two workgroups per CU)
-// ABLATE : timing experiments only (results invalid): 1 = no epilogue, 2 = no hit handling
-template <int KS, int M, int NQB, int WPS, int ABLATE = 0>
-__global__ void __launch_bounds__(kCoarseThreads, WPS)
+template <int KS, int M, int NQB, int WPS>
+__global__ void __launch_bounds__(coarse_waves(KS) * 64, WPS)
 coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
               int n_stages,
               const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments
@@ -221,7 +221,8 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
-    const int qb0 = (blockIdx.x * kCoarseWaves + wave) * NQB;
+    constexpr int WAVES = coarse_waves(KS);
+    const int qb0 = (blockIdx.x * WAVES + wave) * NQB;
     const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue_bytes_per_wave(NQB) + lane * 8);
 
     // Queries of this wave: B fragments, resident for the whole sweep.
@@ -254,17 +255,17 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
         }
     }
 
-    stage_copy(rimg, smem, STAGE, wave, lane);
+    stage_copy(rimg, smem, STAGE, wave, lane, WAVES);
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
 
     for (int st = 0; st < n_stages; ++st) {
         char* cur = smem + (st & 1) * STAGE;
-        if ((ABLATE < 3 || ABLATE == 6) && st + 1 < n_stages)
-            stage_copy(rimg + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane);
+        if (st + 1 < n_stages)
+            stage_copy(rimg + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
 
 #pragma unroll 1
         for (int t = 0; t < TPS; ++t) {
-            const char* tb = (ABLATE == 4) ? smem : cur + t * TB;  // 4: loop-invariant reads, hoisted by the compiler
+            const char* tb = cur + t * TB;
             half8 ah[KS], al[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -288,34 +289,25 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
                 floatx16 acc = contract_main<KS>(ah, bh[qb], c0);
-                if constexpr (ABLATE == 0 || ABLATE >= 5) {
+                {
                     // can any of the 16 x 64 values still beat its lane's threshold after correction?
-                    const float t0 = first_min(acc[0], acc[1]);
-                    const float a0 = min2f(t0, acc[2], t0), a1 = min3f(acc[3], acc[4], acc[5], t0);
+                    const float t0 = first_read(acc[0]);
+                    const float a0 = min3f(t0, acc[1], acc[2], t0), a1 = min3f(acc[3], acc[4], acc[5], t0);
                     const float a2 = min3f(acc[6], acc[7], acc[8], t0), a3 = min3f(acc[9], acc[10], acc[11], t0);
                     const float a4 = min3f(acc[12], acc[13], acc[14], t0);
                     const float m1 = min3f(min3f(a0, a1, a2, t0), a3, min2f(a4, acc[15], t0), t0);
                     if (__builtin_amdgcn_ballot_w64(m1 < thr[qb] + margin[qb]) == 0) continue;
                 }
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
-                if constexpr (ABLATE == 1 || ABLATE == 3 || ABLATE == 4) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
-                    continue;
-                }
                 const unsigned qlane = qwave + qb * (kQueueCap * 512);
                 // 4 x 4 hierarchy of lane-local minima: 10 VALU for 16 values
                 float g[4];
-                const float u0 = first_min(acc[0], acc[1]);
-                g[0] = min3f(u0, acc[2], acc[3], u0);
+                const float u0 = first_read(acc[0]);
+                g[0] = min2f(min3f(u0, acc[1], acc[2], u0), acc[3], u0);
 #pragma unroll
                 for (int k = 1; k < 4; ++k)
                     g[k] = min2f(min3f(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], u0), acc[4 * k + 3], u0);
                 const float mn = min2f(min3f(g[0], g[1], g[2], u0), g[3]);
-                if constexpr (ABLATE == 2) {
-                    asm volatile("" ::"v"(mn));
-                    continue;
-                }
                 if (__builtin_amdgcn_ballot_w64(mn < thr[qb]) != 0) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -330,8 +322,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 }
             }
         }
-        if (ABLATE == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment: no workgroup barrier
-        else if (ABLATE < 3) __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
+        __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
     }
 
 #pragma unroll

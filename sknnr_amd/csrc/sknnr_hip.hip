@@ -12,7 +12,6 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -536,21 +535,14 @@ template <int KS, int M>
 int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
     constexpr int NQB = (KS <= 4) ? 2 : 1;
     constexpr int WPS = (KS <= 2) ? 4 : 2;
-    constexpr int QPB = kCoarseWaves * NQB * 32;
+    constexpr int WAVES = coarse_waves(KS);
+    constexpr int QPB = WAVES * NQB * 32;
     constexpr int TPS = tiles_per_stage(KS);
-    constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS) + (size_t)kCoarseWaves * queue_bytes_per_wave(NQB);
+    constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS) + (size_t)WAVES * queue_bytes_per_wave(NQB);
+    static_assert(1024 % QPB == 0, "query rows are padded to multiples of 1024");
     auto kern = coarse_kernel<KS, M, NQB, WPS>;
-    if constexpr (KS == 2 && M == 6) {  // timing experiments (SKNNR_COARSE_ABLATE=1|2): results are invalid
-        const char* ab = std::getenv("SKNNR_COARSE_ABLATE");
-        if (ab && ab[0] == '1') kern = coarse_kernel<KS, M, NQB, WPS, 1>;
-        if (ab && ab[0] == '2') kern = coarse_kernel<KS, M, NQB, WPS, 2>;
-        if (ab && ab[0] == '3') kern = coarse_kernel<KS, M, NQB, WPS, 3>;
-        if (ab && ab[0] == '4') kern = coarse_kernel<KS, M, NQB, WPS, 4>;
-        if (ab && ab[0] == '5') kern = coarse_kernel<KS, M, NQB, WPS, 5>;
-        if (ab && ab[0] == '6') kern = coarse_kernel<KS, M, NQB, WPS, 6>;
-    }
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(kCoarseThreads), sh, st>>>(
+    kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(WAVES * 64), sh, st>>>(
         ix->rimg.p, ix->n_stages, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
         ix->cand_val.p, ix->cand_idx.p);
     HIP_TRY(hipGetLastError());
@@ -651,7 +643,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         xq_call = ix->xt.p;
     }
     const long cap = std::min(kChunkRows, nq);
-    const long cap_pad = (cap + 511) / 512 * 512;
+    const long cap_pad = (cap + 1023) / 1024 * 1024;
     if (coarse || affine) {
         HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
         HIP_TRY(ix->qnc.ensure(cap_pad));
@@ -685,7 +677,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     HIP_TRY(hipEventRecord(ix->ev_call0, st));
     for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
         const long n = std::min(kChunkRows, nq - c0);
-        const long n_pad = (n + 511) / 512 * 512;
+        const long n_pad = (n + 1023) / 1024 * 1024;
         const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
         if (coarse || affine) {
             int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st);
@@ -957,7 +949,7 @@ extern "C" int sknnr_debug_coarse_matrix(sknnr_index* ix, const double* q, int64
     if (ix->ks == 0) return fail(SKNNR_ERR_UNSUPPORTED, "no coarse image (d > 128)");
     if ((double)nq * (double)ix->n_ref > 16777216.0) return fail(SKNNR_ERR_INVALID, "nq * n_ref must be <= 2^24");
     HIP_TRY(hipSetDevice(ix->device));
-    const long n_pad = (nq + 511) / 512 * 512;
+    const long n_pad = (nq + 1023) / 1024 * 1024;
     HIP_TRY(ix->xstage.ensure((size_t)nq * ix->d));
     HIP_TRY(hipMemcpy(ix->xstage.p, q, (size_t)nq * ix->d * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(ix->qimg.ensure((size_t)(n_pad / 32) * 2 * ix->ks * 64));
