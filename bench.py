@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (dist, idx)")
     ap.add_argument("--predict", action="store_true", help="also time predict (distance weights) as an extra")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (self-test of the N>1 path)")
     return ap.parse_args()
 
 
@@ -113,9 +115,11 @@ def main():
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from sknnr_amd import synth
     from sknnr_amd._engine import KNNEngine
@@ -141,14 +145,14 @@ def main():
 
     def step():
         d, i = eng.kneighbors(q, k, apply_affine=True, deterministic=True, row_offset=rank * nq)
-        if world > 1 and not args.no_gather:
+        if use_dist and not args.no_gather:
             d = all_gather_rows(d, world * nq)
             i = all_gather_rows(i, world * nq)
         return d, i
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +171,7 @@ def main():
     coarse_ms, kernel_ms = st["last_coarse_ms"], st["last_kernel_ms"]
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -217,7 +221,7 @@ def main():
             "config": {
                 "workload": f"GNN-style kneighbors: affine {args.dims}->{d_t} (CCA fit on synthetic refs) + "
                             f"{nq} query rows/GPU x {args.refs} refs x {d_t} dims, k={k}, deterministic reorder, "
-                            "float64 (dist, idx) out" + ("" if world == 1 or args.no_gather else " + RCCL all-gather"),
+                            "float64 (dist, idx) out" + (" + RCCL all-gather" if use_dist and not args.no_gather else ""),
                 "rows_per_gpu": nq, "n_ref": args.refs, "d_in": args.dims, "d_t": int(d_t), "k": k,
                 "parallelism": f"query-row shards x{world}",
             },
@@ -240,7 +244,7 @@ def main():
             }
             result["speedup_vs_cpu"] = value / base["value"]
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

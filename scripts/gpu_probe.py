@@ -88,6 +88,13 @@ def timing(nq, n_ref, d, k, reps=3):
               f"coarse {s['last_coarse_ms']:.1f} ms -> {nq / dt / 1e6:.2f} Mq/s, "
               f"coarse TF(alg) {2.0 * nq * n_ref * d / (s['last_coarse_ms'] * 1e-3) / 1e12:.1f}, "
               f"fallbacks {s['exact_fallbacks']}")
+    # host-buffer entry point (PCIe staging included): numpy in, numpy out
+    n_h = min(nq, 2_000_000)
+    qh = q[:n_h].cpu().numpy()
+    t0 = time.perf_counter()
+    ix.kneighbors_host(qh, o)
+    dt = time.perf_counter() - t0
+    print(f"   host buffers (PCIe inclusive), {n_h} rows: {dt * 1e3:.1f} ms -> {n_h / dt / 1e6:.2f} Mq/s")
     # spot parity on a slice
     sl = slice(0, 2048)
     od, oi = O.kneighbors(x_ref, q[sl].cpu().numpy(), k, "expanded")
