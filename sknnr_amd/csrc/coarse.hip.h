@@ -43,9 +43,14 @@ __host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 8 :
 // Row of the 32x32 accumulator held in register r of a lane in half h (guide section 3).
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// waves per workgroup: 16 (one 1024-thread workgroup per CU, 4 waves per SIMD at <= 128 VGPR) for
-// KS <= 2; 8 (2 waves per SIMD at <= 256 VGPR) for wider features
-__host__ __device__ constexpr int coarse_waves(int ks) { return ks <= 2 ? 16 : 8; }
+// Launch geometry by feature width (KS) and list length (M):
+//   narrow features and short lists: 16 waves (one 1024-thread workgroup per CU, 4 waves per SIMD at
+//   <= 128 VGPR); otherwise 8 waves (2 per SIMD, <= 256 VGPR).  Two 32-query blocks per wave while the
+//   registers allow it.
+__host__ __device__ constexpr bool coarse_is_light(int ks, int m) { return ks <= 2 && m <= 16; }
+__host__ __device__ constexpr int coarse_waves(int ks, int m) { return coarse_is_light(ks, m) ? 16 : 8; }
+__host__ __device__ constexpr int coarse_wps(int ks, int m) { return coarse_is_light(ks, m) ? 4 : 2; }
+__host__ __device__ constexpr int coarse_nqb(int ks, int m) { return (ks <= 4 && m <= 8) ? 2 : 1; }
 
 // v_min3_f32 / v_min_f32 as raw instructions: the compiler would put a canonicalising
 // v_max in front of every fminf operand that comes out of an MFMA (16 extra VALU per tile).
@@ -200,12 +205,10 @@ __device__ __forceinline__ void flush_queue(float (&vals)[M], int (&idxs)[M], fl
     thr = min2f(own, other);
 }
 
-// KS  : 16-wide K-steps per split part (padded feature count / 16)
-// M   : list length per lane
-// NQB : 32-query blocks per wave
-// WPS : waves per SIMD the register budget is sized for (4: two workgroups per CU)
-template <int KS, int M, int NQB, int WPS>
-__global__ void __launch_bounds__(coarse_waves(KS) * 64, WPS)
+// KS : 16-wide K-steps per split part (padded feature count / 16)
+// M  : list length per lane (6, 8, 16 or 32: up to 5, 7, 15 or 31 neighbours searched)
+template <int KS, int M>
+__global__ void __launch_bounds__(coarse_waves(KS, M) * 64, coarse_wps(KS, M))
 coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
               int n_stages,
               const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments
@@ -221,7 +224,8 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
-    constexpr int WAVES = coarse_waves(KS);
+    constexpr int WAVES = coarse_waves(KS, M);
+    constexpr int NQB = coarse_nqb(KS, M);
     const int qb0 = (blockIdx.x * WAVES + wave) * NQB;
     const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue_bytes_per_wave(NQB) + lane * 8);
 

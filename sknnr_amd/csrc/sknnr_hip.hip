@@ -113,8 +113,6 @@ struct DevBuf {
     }
 };
 
-constexpr int kListLen = 8;            // M of the production coarse kernel
-constexpr int kCoarseMaxKK = kListLen - 1;
 constexpr int kMaxKs = 8;              // coarse path: d <= 128
 constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk
 constexpr int kScanMaxKK = 192;
@@ -533,14 +531,14 @@ int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool aff
 
 template <int KS, int M>
 int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
-    constexpr int NQB = (KS <= 4) ? 2 : 1;
-    constexpr int WPS = (KS <= 2) ? 4 : 2;
-    constexpr int WAVES = coarse_waves(KS);
+    constexpr int NQB = coarse_nqb(KS, M);
+    constexpr int WAVES = coarse_waves(KS, M);
     constexpr int QPB = WAVES * NQB * 32;
     constexpr int TPS = tiles_per_stage(KS);
     constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS) + (size_t)WAVES * queue_bytes_per_wave(NQB);
     static_assert(1024 % QPB == 0, "query rows are padded to multiples of 1024");
-    auto kern = coarse_kernel<KS, M, NQB, WPS>;
+    static_assert(sh <= 160 * 1024, "LDS budget");
+    auto kern = coarse_kernel<KS, M>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(WAVES * 64), sh, st>>>(
         ix->rimg.p, ix->n_stages, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
@@ -549,8 +547,10 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
     return SKNNR_OK;
 }
 
-// list length per lane for kk neighbours searched: one spare slot keeps the certificate cheap
-int coarse_list_len(int kk) { return kk <= 5 ? 6 : 8; }
+// List length per lane for kk neighbours searched: at least one spare slot keeps the certificate
+// cheap.  kk > 31 is outside the MFMA envelope (exact scan for the whole call).
+constexpr int kCoarseMaxKK = 31;
+int coarse_list_len(int kk) { return kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32)); }
 
 template <int M>
 int launch_coarse_m(sknnr_index* ix, long nq_pad, hipStream_t st) {
@@ -568,7 +568,24 @@ int launch_coarse_m(sknnr_index* ix, long nq_pad, hipStream_t st) {
 }
 
 int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, hipStream_t st) {
-    return m_list == 6 ? launch_coarse_m<6>(ix, nq_pad, st) : launch_coarse_m<8>(ix, nq_pad, st);
+    switch (m_list) {
+        case 6: return launch_coarse_m<6>(ix, nq_pad, st);
+        case 8: return launch_coarse_m<8>(ix, nq_pad, st);
+        case 16: return launch_coarse_m<16>(ix, nq_pad, st);
+        case 32: return launch_coarse_m<32>(ix, nq_pad, st);
+    }
+    return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for list length %d", m_list);
+}
+
+template <int M>
+void launch_finalize_m(const FinalizeArgs& f, long n, hipStream_t st) {
+    const long threads = n * 2 * M;
+    finalize_kernel<M><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(f);
+}
+void launch_finalize(const FinalizeArgs& f, long n, hipStream_t st) {
+    if (f.m_list <= 8) launch_finalize_m<8>(f, n, st);
+    else if (f.m_list == 16) launch_finalize_m<16>(f, n, st);
+    else launch_finalize_m<32>(f, n, st);
 }
 
 int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int* count, long max_items,
@@ -649,8 +666,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         HIP_TRY(ix->qnc.ensure(cap_pad));
     }
     if (coarse) {
-        HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * kListLen));
-        HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * kListLen));
+        HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * coarse_list_len(kk)));
+        HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * coarse_list_len(kk)));
         HIP_TRY(ix->fail_list.ensure(nq));
         HIP_TRY(hipMemsetAsync(ix->fail_count.p, 0, 16, st));
     }
@@ -714,8 +731,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         f.fail_list = ix->fail_list.p;
         f.fail_count = ix->fail_count.p;
         f.fail_base = (int)c0;
-        const long threads = n * 2 * kListLen;
-        finalize_kernel<kListLen><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(f);
+        launch_finalize(f, n, st);
         HIP_TRY(hipGetLastError());
     }
     // One exact scan per call: the rows the finaliser could not certify (call-relative ids), or

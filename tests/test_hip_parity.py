@@ -136,8 +136,10 @@ def test_integer_features_many_exact_ties(N, O, deterministic, k):
     ix.close()
 
 
-@pytest.mark.parametrize("k", [9, 16, 40])
-def test_large_k_uses_the_exact_scan(N, O, k):
+@pytest.mark.parametrize("k", [9, 14, 16, 30, 31, 40])
+def test_larger_k(N, O, k):
+    """k + self <= 31 stays on the MFMA path (lists of 16 / 32 per lane); beyond that the whole
+    call is answered by the exact scan."""
     x_ref, y, x_q = _synth(700, 300, 20)
     ix = N.Index(x_ref, y)
     dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k))
@@ -147,7 +149,25 @@ def test_large_k_uses_the_exact_scan(N, O, k):
     dist, idx = ix.kneighbors_host(None, ix.make_opts(k, exclude_self=True), nq=700)
     od, oi = O.kneighbors(x_ref, None, k, "expanded")
     np.testing.assert_array_equal(idx, oi)
-    assert ix.stats()["exact_only_queries"] == 1000
+    np.testing.assert_array_equal(dist, od)
+    st = ix.stats()
+    if k == 40:
+        assert st["exact_only_queries"] == 1000
+    elif k + 1 <= 31:
+        assert st["coarse_queries"] == 1000 and st["exact_fallbacks"] <= 20, st
+    ix.close()
+
+
+@pytest.mark.parametrize("d", [16, 64])
+def test_larger_k_wider(N, O, d):
+    x_ref, y, x_q = _synth(3000, 1500, d)
+    ix = N.Index(x_ref, y)
+    for k in (10, 20):
+        dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k))
+        od, oi = O.kneighbors(x_ref, x_q, k, "expanded")
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+    assert ix.stats()["exact_only_queries"] == 0
     ix.close()
 
 
