@@ -143,12 +143,37 @@ def main():
     nq, k = args.rows, args.k
     stream = torch.cuda.current_stream()
 
+    gather_chunk = 2_500_000  # rows per all-gather: chunk i travels while chunk i+1 is computed
+    comm_stream = torch.cuda.Stream() if use_dist else None
+
     def step():
-        d, i = eng.kneighbors(q, k, apply_affine=True, deterministic=True, row_offset=rank * nq)
-        if use_dist and not args.no_gather:
-            d = all_gather_rows(d, world * nq)
-            i = all_gather_rows(i, world * nq)
-        return d, i
+        if not (use_dist and not args.no_gather):
+            return eng.kneighbors(q, k, apply_affine=True, deterministic=True, row_offset=rank * nq)
+        # N > 1: every rank answers its own block (global row offset rank * nq) chunk by chunk; the
+        # RCCL all-gather of a finished chunk runs on a side stream under the next chunk's kernels.
+        d_all = torch.empty((world, nq, k), dtype=torch.float64, device="cuda")
+        i_all = torch.empty((world, nq, k), dtype=torch.int64, device="cuda")
+        works = []
+        for a in range(0, nq, gather_chunk):
+            b = min(nq, a + gather_chunk)
+            d, i = eng.kneighbors(q[a:b], k, apply_affine=True, deterministic=True, row_offset=rank * nq + a)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(done)
+                d_recv = torch.empty((world, b - a, k), dtype=torch.float64, device="cuda")
+                i_recv = torch.empty((world, b - a, k), dtype=torch.int64, device="cuda")
+                w1 = dist.all_gather_into_tensor(d_recv, d, async_op=True)
+                w2 = dist.all_gather_into_tensor(i_recv, i, async_op=True)
+                works.append((a, b, d, i, d_recv, i_recv, w1, w2))
+        for a, b, _d, _i, d_recv, i_recv, w1, w2 in works:
+            w1.wait()
+            w2.wait()
+            with torch.cuda.stream(comm_stream):
+                d_all[:, a:b] = d_recv
+                i_all[:, a:b] = i_recv
+        torch.cuda.current_stream().wait_stream(comm_stream)
+        return d_all.view(world * nq, k), i_all.view(world * nq, k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -235,8 +260,8 @@ def main():
             q_host = q[:n_s].cpu().numpy()
             base, (cd, ci) = cpu_baseline(x_ref_t, center, proj, q_host, k)
             result["cpu_baseline"] = base
-            gi = i_out[:n_s].cpu().numpy()
-            gd = d_out[:n_s].cpu().numpy()
+            gi = i_out[rank * nq: rank * nq + n_s].cpu().numpy() if use_dist and not args.no_gather else i_out[:n_s].cpu().numpy()
+            gd = d_out[rank * nq: rank * nq + n_s].cpu().numpy() if use_dist and not args.no_gather else d_out[:n_s].cpu().numpy()
             rel = np.abs(gd - cd) / np.maximum(np.abs(cd), 1e-300)
             result["parity_vs_cpu_reference"] = {
                 "rows": int(n_s), "index_rows_equal": int((gi == ci).all(axis=1).sum()),

@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// exact_scan_kernel: the reference's engine itself, one wavefront per query.
+// exact_scan_kernel: the reference's engine itself, one workgroup per query.
 //
 // Every reference row is visited in ascending index order, its float64 distance pushed
 // into a fixed-size max-heap that rejects values equal to its root, the heap is sorted with
@@ -364,10 +364,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 //
 // Used for (a) queries whose MFMA certificate failed, (b) queries with an exact tie at the
 // k-th slot (or, without deterministic ordering, any tie among the k), (c) calls outside the
-// MFMA envelope (large k, very wide features).  64 references per step: each lane evaluates
-// one distance from the transposed float64 copy of the references (coalesced), a ballot
-// against the heap's root finds the (rare) lanes to push, lane 0 replays those pushes in
-// index order on the heap in LDS.
+// MFMA envelope (large k, very wide features).
 // ---------------------------------------------------------------------------------------
 struct ScanArgs {
     SelectArgs s;       // s.ref is unused here; refT below
@@ -447,104 +444,113 @@ __device__ void dual_quicksort_ref(double* v0, int* x0, int n0, int* stack) {
     }
 }
 
-// Per-wave LDS slice: xs[d] | hv[KK] | hi[KK] | stack[2*KK+4]
-__host__ __device__ inline size_t scan_wave_bytes(int d, int kk) {
+// Workgroup LDS: xs[d] | hv[KK] | hi[KK] | stack[2*KK+4] | d2[2][256]
+__host__ __device__ inline size_t scan_block_bytes(int d, int kk) {
     size_t b = 8 * (size_t)((d + 1) & ~1) + 8 * (size_t)kk + 4 * (size_t)(kk + (kk & 1));
     b += 4 * (size_t)((2 * kk + 4 + 1) & ~1);
-    return (b + 15) & ~(size_t)15;
+    b = (b + 15) & ~(size_t)15;
+    return b + 2 * 256 * 8;
 }
 
 constexpr int kScanWaves = 4;
 
+// One workgroup (4 waves) per query.  Per step of 256 references every lane evaluates ONE float64
+// distance (column j of the transposed copy: coalesced; up to 32 features loaded at once so a
+// step is a single memory round trip), the 256 values go to LDS, and after the workgroup barrier
+// wave 0 offers them to the heap in index order while the other waves already work on the next
+// step (two LDS buffers; wave 0 has finished replaying step s-1 before it arrives at barrier s).
 __global__ void __launch_bounds__(kScanWaves * 64) exact_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const SelectArgs& s = a.s;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     const int KK = s.kk;
-    char* mine = smem_raw + (size_t)wave * scan_wave_bytes(s.d, KK);
-    double* xs = (double*)mine;
+    double* xs = (double*)smem_raw;
     double* hv = xs + ((s.d + 1) & ~1);
     int* hi = (int*)(hv + KK);
     int* stack = hi + KK + (KK & 1);
+    double* d2buf = (double*)(smem_raw + scan_block_bytes(s.d, KK) - 2 * 256 * 8);
 
     const long n_items = a.list ? (long)*a.count : s.nq;
-    const long wave_id = (long)blockIdx.x * kScanWaves + wave;
-    const long n_waves = (long)gridDim.x * kScanWaves;
-    for (long f = wave_id; f < n_items; f += n_waves) {
+    for (long f = blockIdx.x; f < n_items; f += gridDim.x) {
         const long q = a.list ? (long)a.list[f] : f;
-        for (int c = lane; c < s.d; c += 64) xs[c] = s.xq[q * s.d + c];
-        for (int i = lane; i < KK; i += 64) {
+        __syncthreads();  // previous query's LDS state is dead
+        for (int c = tid; c < s.d; c += kScanWaves * 64) xs[c] = s.xq[q * s.d + c];
+        for (int i = tid; i < KK; i += kScanWaves * 64) {
             hv[i] = DBL_MAX;
             hi[i] = 0;
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         double qn = 0.0;
         if (s.formula == 0)
             for (int c = 0; c < s.d; ++c) qn = fma(xs[c], xs[c], qn);
-        double root = DBL_MAX;
+        double root = DBL_MAX;  // meaningful in wave 0 only
 
-        // 256 references per step: every lane evaluates 4 distances (columns j0 + lane + 64u of the
-        // transposed copy, coalesced) with 32 independent loads in flight per 8 features, then the
-        // four 64-wide groups are offered to the heap in index order.
-        for (int j0 = 0; j0 < s.n_ref; j0 += 256) {
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            const size_t ld = (size_t)s.n_ref;
+        const size_t ld = (size_t)s.n_ref;
+        int step = 0;
+        for (int j0 = 0; j0 < s.n_ref; j0 += 256, ++step) {
+            const int j = j0 + tid;
+            const double* col = a.refT + (j < s.n_ref ? j : 0);
+            double acc = 0.0;
             int c = 0;
-            for (; c + 8 <= s.d; c += 8) {
-                double r[4][8];
+            for (; c + 32 <= s.d; c += 32) {
+                double r[32];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + lane + 64 * u;
-                    const double* col = a.refT + (j < s.n_ref ? j : 0);
+                for (int w = 0; w < 32; ++w) r[w] = col[(size_t)(c + w) * ld];
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) r[u][w] = col[(size_t)(c + w) * ld];
+                for (int w = 0; w < 32; ++w) {
+                    if (s.formula == 0) acc = fma(xs[c + w], r[w], acc);
+                    else { const double t = xs[c + w] - r[w]; acc = acc + t * t; }
                 }
+            }
+            for (; c + 8 <= s.d; c += 8) {
+                double r[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int w = 0; w < 8; ++w) r[w] = col[(size_t)(c + w) * ld];
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        if (s.formula == 0) acc[u] = fma(xs[c + w], r[u][w], acc[u]);
-                        else { const double t = xs[c + w] - r[u][w]; acc[u] = acc[u] + t * t; }
-                    }
+                for (int w = 0; w < 8; ++w) {
+                    if (s.formula == 0) acc = fma(xs[c + w], r[w], acc);
+                    else { const double t = xs[c + w] - r[w]; acc = acc + t * t; }
                 }
             }
             for (; c < s.d; ++c) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + lane + 64 * u;
-                    const double rv = a.refT[(size_t)c * ld + (j < s.n_ref ? j : 0)];
-                    if (s.formula == 0) acc[u] = fma(xs[c], rv, acc[u]);
-                    else { const double t = xs[c] - rv; acc[u] = acc[u] + t * t; }
+                const double rv = col[(size_t)c * ld];
+                if (s.formula == 0) acc = fma(xs[c], rv, acc);
+                else { const double t = xs[c] - rv; acc = acc + t * t; }
+            }
+            double d2 = INFINITY;
+            if (j < s.n_ref) {
+                if (s.formula == 0) {
+                    d2 = qn + (-2.0 * acc) + s.rn[j];
+                    d2 = d2 > 0.0 ? d2 : 0.0;
+                } else {
+                    d2 = acc;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + lane + 64 * u;
-                double d2 = INFINITY;
-                if (j < s.n_ref) {
-                    if (s.formula == 0) {
-                        d2 = qn + (-2.0 * acc[u]) + s.rn[j];
-                        d2 = d2 > 0.0 ? d2 : 0.0;
-                    } else {
-                        d2 = acc[u];
-                    }
-                }
-                unsigned long long m = __builtin_amdgcn_ballot_w64(d2 < root);
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const double v = __shfl(d2, b, 64);
-                    if (v < root) {  // the root may have dropped since the ballot
-                        if (lane == 0) heap_push_ref(hv, hi, KK, v, j0 + 64 * u + b);
-                        __builtin_amdgcn_wave_barrier();
-                        root = hv[0];
+            double* buf = d2buf + (step & 1) * 256;
+            buf[tid] = d2;
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll 1
+                for (int u = 0; u < 4; ++u) {
+                    const double v64 = buf[64 * u + lane];
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(v64 < root);
+                    while (m) {
+                        const int bit = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const double v = __shfl(v64, bit, 64);
+                        if (v < root) {  // the root may have dropped since the ballot
+                            if (lane == 0) heap_push_ref(hv, hi, KK, v, j0 + 64 * u + bit);
+                            __builtin_amdgcn_wave_barrier();
+                            root = hv[0];
+                        }
                     }
                 }
             }
         }
 
-        if (lane == 0) {
+        if (tid == 0) {
             dual_quicksort_ref(hv, hi, KK, stack);
             // drop self (X=None), sqrt, reorder: serial over <= KK entries
             const long self_id = s.row_offset + q;
@@ -573,19 +579,19 @@ __global__ void __launch_bounds__(kScanWaves * 64) exact_scan_kernel(ScanArgs a)
                     const double k0 = round_key(dv / row_scale, s.pow10, s.pow10_is_divisor);
                     long k1 = (long)iv - self_id;
                     k1 = k1 < 0 ? -k1 : k1;
-                    int j = i - 1;
-                    while (j >= 0) {
-                        const double k0j = round_key(hv[j] / row_scale, s.pow10, s.pow10_is_divisor);
-                        long k1j = (long)hi[j] - self_id;
+                    int jj = i - 1;
+                    while (jj >= 0) {
+                        const double k0j = round_key(hv[jj] / row_scale, s.pow10, s.pow10_is_divisor);
+                        long k1j = (long)hi[jj] - self_id;
                         k1j = k1j < 0 ? -k1j : k1j;
-                        const bool greater = (k0j > k0) || (k0j == k0 && (k1j > k1 || (k1j == k1 && hi[j] > iv)));
+                        const bool greater = (k0j > k0) || (k0j == k0 && (k1j > k1 || (k1j == k1 && hi[jj] > iv)));
                         if (!greater) break;
-                        hv[j + 1] = hv[j];
-                        hi[j + 1] = hi[j];
-                        --j;
+                        hv[jj + 1] = hv[jj];
+                        hi[jj + 1] = hi[jj];
+                        --jj;
                     }
-                    hv[j + 1] = dv;
-                    hi[j + 1] = iv;
+                    hv[jj + 1] = dv;
+                    hi[jj + 1] = iv;
                 }
             }
             for (int i = 0; i < n; ++i) {
@@ -593,7 +599,6 @@ __global__ void __launch_bounds__(kScanWaves * 64) exact_scan_kernel(ScanArgs a)
                 s.out_idx[q * s.k + i] = hi[i];
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 

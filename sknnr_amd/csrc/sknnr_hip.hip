@@ -590,13 +590,13 @@ void launch_finalize(const FinalizeArgs& f, long n, hipStream_t st) {
 
 int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int* count, long max_items,
                 hipStream_t st) {
-    const size_t sh = kScanWaves * scan_wave_bytes(s.d, s.kk);
+    const size_t sh = scan_block_bytes(s.d, s.kk);
     if (sh > 150 * 1024)
         return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", s.k, s.d);
     ScanArgs a{s, ix->refT.p, list, count};
     HIP_TRY(hipFuncSetAttribute((const void*)exact_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    // 16 waves per CU keep the float64 pipes busy; queries are dealt to waves round-robin
-    const long blocks = std::max<long>(1, std::min<long>((max_items + kScanWaves - 1) / kScanWaves, 256L * 4));
+    // one 4-wave workgroup per query at a time; 4 workgroups per CU keep the float64 pipes busy
+    const long blocks = std::max<long>(1, std::min<long>(max_items, 256L * 4));
     exact_scan_kernel<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
     HIP_TRY(hipGetLastError());
     return SKNNR_OK;
