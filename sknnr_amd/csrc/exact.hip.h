@@ -124,6 +124,88 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
     if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? qn : 0.0;
 }
 
+// Register-resident variant for narrow feature spaces (16*KS <= 64 transformed features): one
+// thread per query, all accumulators in VGPRs, no LDS -> occupancy is set by registers only
+// (the LDS-staged kernel above holds 264 B of LDS per query and tops out at ~9 waves per CU).
+// Each input feature is read once (16-byte loads when rows are 16-byte aligned) and scattered
+// into the 16*KS accumulators with wave-uniform (scalar-loaded) projector rows; the fma order
+// per output is the same k-ordered chain.
+template <int KS>
+__global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
+    constexpr int DP = 16 * KS;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = q < a.nq;
+    double acc[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) acc[j] = 0.0;
+    if (live) {
+        const double* xr = a.x + q * a.d_in;
+        if (a.proj) {
+            int c = 0;
+            if ((a.d_in & 1) == 0) {
+                const double2* x2 = (const double2*)xr;
+                for (; c < a.d_in; c += 2) {
+                    const double2 xv = x2[c >> 1];
+                    double v0 = xv.x, v1 = xv.y;
+                    if (a.center) { v0 = v0 - a.center[c]; v1 = v1 - a.center[c + 1]; }
+                    if (a.scale) { v0 = v0 / a.scale[c]; v1 = v1 / a.scale[c + 1]; }
+                    const double* p0 = a.proj + (long)c * DP;
+#pragma unroll
+                    for (int j = 0; j < DP; ++j) acc[j] = fma(v0, p0[j], acc[j]);
+#pragma unroll
+                    for (int j = 0; j < DP; ++j) acc[j] = fma(v1, p0[DP + j], acc[j]);
+                }
+            }
+            for (; c < a.d_in; ++c) {
+                double v = xr[c];
+                if (a.center) v = v - a.center[c];
+                if (a.scale) v = v / a.scale[c];
+                const double* pc = a.proj + (long)c * DP;
+#pragma unroll
+                for (int j = 0; j < DP; ++j) acc[j] = fma(v, pc[j], acc[j]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                if (k < a.d) {
+                    double v = xr[k];
+                    if (a.center) v = v - a.center[k];
+                    if (a.scale) v = v / a.scale[k];
+                    acc[k] = v;
+                }
+            }
+        }
+        if (a.xt) {
+#pragma unroll
+            for (int k = 0; k < DP; ++k)
+                if (k < a.d) a.xt[q * a.d + k] = acc[k];
+        }
+    }
+    if (!a.qimg) return;
+    const long qb = q >> 5;
+    const int col = (int)(q & 31);
+    double qn = 0.0;
+#pragma unroll
+    for (int jc = 0; jc < 2 * KS; ++jc) {
+        half8 hi, lo;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = jc * 8 + jj;
+            const double b = (live && k < a.d) ? a.s * (acc[k] - a.mu[k]) : 0.0;
+            qn = fma(b, b, qn);
+            const _Float16 h = (_Float16)(float)b;
+            hi[jj] = h;
+            lo[jj] = (_Float16)(float)(b - (double)h);
+        }
+        if (q < a.nq_pad) {
+            const int step = jc >> 1, hh = jc & 1;
+            a.qimg[((size_t)(qb * 2 + 0) * KS + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, hi);
+            a.qimg[((size_t)(qb * 2 + 1) * KS + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, lo);
+        }
+    }
+    if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? qn : 0.0;
+}
+
 // ---------------------------------------------------------------------------------------
 // The reference's pair distance in float64.
 // formula 0: |x|^2 + (-2 x.y) + |y|^2, clamped at 0   (_argkmin.pyx.tp:492-502)

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -510,7 +511,16 @@ int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool aff
     a.qnc = ix->qnc.p;
     const int ldx = a.d_in | 1;
     const size_t lim = 150 * 1024;
-    if ((size_t)256 * ldx * 8 <= lim) {
+    if (ix->ks <= 4 && !std::getenv("SKNNR_PREP_LDS")) {
+        // narrow feature spaces: register-resident kernel (no LDS, high occupancy)
+        const dim3 grid((unsigned)(nq_pad / 256)), block(256);
+        switch (ix->ks) {
+            case 1: prep_queries_direct_kernel<1><<<grid, block, 0, st>>>(a); break;
+            case 2: prep_queries_direct_kernel<2><<<grid, block, 0, st>>>(a); break;
+            case 3: prep_queries_direct_kernel<3><<<grid, block, 0, st>>>(a); break;
+            default: prep_queries_direct_kernel<4><<<grid, block, 0, st>>>(a); break;
+        }
+    } else if ((size_t)256 * ldx * 8 <= lim) {
         const size_t sh = (size_t)256 * ldx * 8;
         HIP_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         prep_queries_kernel<256><<<dim3((unsigned)(nq_pad / 256)), dim3(256), sh, st>>>(a);
