@@ -292,7 +292,9 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
+                __builtin_amdgcn_s_setprio(1);
                 floatx16 acc = contract_main<KS>(ah, bh[qb], c0);
+                __builtin_amdgcn_s_setprio(0);
                 {
                     // can any of the 16 x 64 values still beat its lane's threshold after correction?
                     const float t0 = first_read(acc[0]);
@@ -302,7 +304,9 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                     const float m1 = min3f(min3f(a0, a1, a2, t0), a3, min2f(a4, acc[15], t0), t0);
                     if (__builtin_amdgcn_ballot_w64(m1 < thr[qb] + margin[qb]) == 0) continue;
                 }
+                __builtin_amdgcn_s_setprio(1);
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
+                __builtin_amdgcn_s_setprio(0);
                 const unsigned qlane = qwave + qb * (kQueueCap * 512);
                 // 4 x 4 hierarchy of lane-local minima: 10 VALU for 16 values
                 float g[4];

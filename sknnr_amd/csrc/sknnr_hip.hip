@@ -115,7 +115,8 @@ struct DevBuf {
 };
 
 constexpr int kMaxKs = 8;              // coarse path: d <= 128
-constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk
+constexpr long kRowQuantum = 1024;  // query-row padding: multiple of every coarse geometry (1024, 512, 256 rows per workgroup)
+constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk (multiple of kRowQuantum)
 constexpr int kScanMaxKK = 192;
 // Error budget of the split contraction, in units of 2^-24 (|q'| + max|r'|)^2:
 // eps_units(ks) = 8 + 4 ks.  Measured worst case on gfx950 over 5e5 pairs per shape
@@ -546,7 +547,7 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
     constexpr int QPB = WAVES * NQB * 32;
     constexpr int TPS = tiles_per_stage(KS);
     constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS) + (size_t)WAVES * queue_bytes_per_wave(NQB);
-    static_assert(1024 % QPB == 0, "query rows are padded to multiples of 1024");
+    static_assert(kRowQuantum % QPB == 0, "query rows are padded to multiples of kRowQuantum");
     static_assert(sh <= 160 * 1024, "LDS budget");
     auto kern = coarse_kernel<KS, M>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
@@ -670,7 +671,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         xq_call = ix->xt.p;
     }
     const long cap = std::min(kChunkRows, nq);
-    const long cap_pad = (cap + 1023) / 1024 * 1024;
+    const long cap_pad = (cap + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
     if (coarse || affine) {
         HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
         HIP_TRY(ix->qnc.ensure(cap_pad));
@@ -704,7 +705,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     HIP_TRY(hipEventRecord(ix->ev_call0, st));
     for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
         const long n = std::min(kChunkRows, nq - c0);
-        const long n_pad = (n + 1023) / 1024 * 1024;
+        const long n_pad = (n + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
         const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
         if (coarse || affine) {
             int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st);
@@ -975,7 +976,7 @@ extern "C" int sknnr_debug_coarse_matrix(sknnr_index* ix, const double* q, int64
     if (ix->ks == 0) return fail(SKNNR_ERR_UNSUPPORTED, "no coarse image (d > 128)");
     if ((double)nq * (double)ix->n_ref > 16777216.0) return fail(SKNNR_ERR_INVALID, "nq * n_ref must be <= 2^24");
     HIP_TRY(hipSetDevice(ix->device));
-    const long n_pad = (nq + 1023) / 1024 * 1024;
+    const long n_pad = (nq + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
     HIP_TRY(ix->xstage.ensure((size_t)nq * ix->d));
     HIP_TRY(hipMemcpy(ix->xstage.p, q, (size_t)nq * ix->d * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(ix->qimg.ensure((size_t)(n_pad / 32) * 2 * ix->ks * 64));
