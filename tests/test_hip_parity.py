@@ -340,6 +340,52 @@ def test_reference_goldens_synthetic(N, d, dup):
     ix.close()
 
 
+def test_chunk_boundaries_and_row_offsets_in_one_big_call(N, O):
+    """More query rows than one workspace chunk (4,194,304): rows around the chunk boundary, the
+    last rows and rows whose tie-break depends on their global position must match the oracle."""
+    import torch
+
+    from sknnr_amd import synth
+    from sknnr_amd._engine import KNNEngine
+
+    n_ref, d, k = 3000, 8, 3
+    nq = 4194304 + 70001
+    x_ref = synth.make_features(n_ref, d, seed=0)
+    x_ref[1] = x_ref[0]  # an exact duplicate pair: |idx - row| decides their order for nearby queries
+    eng = KNNEngine(x_ref)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xq = torch.randn((nq, d), dtype=torch.float64, device="cuda", generator=g) @ torch.tensor(
+        synth.mixing_matrix(d), device="cuda")
+    probe = [0, 1, 4194303, 4194304, 4194305, nq - 1]
+    for r in probe:
+        xq[r] = torch.as_tensor(x_ref[0], device="cuda")  # equidistant to rows 0 and 1
+    dist, idx = eng.kneighbors(xq, k, row_offset=0)
+    for a, b in ((0, 2000), (4194304 - 1000, 4194304 + 1000), (nq - 2000, nq)):
+        od, oi = O.kneighbors(x_ref, xq[a:b].cpu().numpy(), k, "expanded", row_offset=a)
+        np.testing.assert_array_equal(idx[a:b].cpu().numpy(), oi)
+        np.testing.assert_array_equal(dist[a:b].cpu().numpy(), od)
+    got = idx[probe, :2].cpu().numpy().tolist()
+    assert got[0] == [0, 1] and got[1] == [1, 0]          # rows 0 and 1: |idx - row| picks the own index first
+    assert all(p == [1, 0] for p in got[2:])              # far rows: 1 is closer to the row number
+    eng.close()
+
+
+def test_two_indexes_alive_and_reused(N, O):
+    """Handles are independent and reusable across calls of different shapes."""
+    a_ref, a_y, a_q = _synth(900, 300, 12)
+    b_ref, b_y, b_q = _synth(1700, 500, 40)
+    ia, ib = N.Index(a_ref, a_y), N.Index(b_ref, b_y)
+    for _ in range(2):
+        for ix, ref, q in ((ia, a_ref, a_q), (ib, b_ref, b_q), (ia, a_ref, a_q[:7])):
+            for k in (2, 5):
+                dist, idx = ix.kneighbors_host(q, ix.make_opts(k))
+                od, oi = O.kneighbors(ref, q, k, "expanded")
+                np.testing.assert_array_equal(idx, oi)
+                np.testing.assert_array_equal(dist, od)
+    ia.close()
+    ib.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE-size properties (no CPU reference at these sizes)
 # ---------------------------------------------------------------------------------------------
