@@ -100,7 +100,7 @@ __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], fl
 // handful of instructions; the 44-instruction sorted insertion runs later, for all lanes of
 // the wave at once (the flush), instead of once per hit with one or two lanes active.
 constexpr int kQueueCap = 4;
-constexpr int kQueueFlushAt = 2;
+constexpr int kQueueFlushAt = 3;
 __host__ __device__ constexpr int queue_bytes_per_wave(int nqb) { return nqb * kQueueCap * 64 * 8; }
 
 // The three-product split contraction of one 32-ref x 32-query tile, in two stages:
@@ -295,39 +295,35 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 __builtin_amdgcn_s_setprio(1);
                 floatx16 acc = contract_main<KS>(ah, bh[qb], c0);
                 __builtin_amdgcn_s_setprio(0);
-                {
-                    // can any of the 16 x 64 values still beat its lane's threshold after correction?
-                    const float t0 = first_read(acc[0]);
-                    const float a0 = min3f(t0, acc[1], acc[2], t0), a1 = min3f(acc[3], acc[4], acc[5], t0);
-                    const float a2 = min3f(acc[6], acc[7], acc[8], t0), a3 = min3f(acc[9], acc[10], acc[11], t0);
-                    const float a4 = min3f(acc[12], acc[13], acc[14], t0);
-                    const float m1 = min3f(min3f(a0, a1, a2, t0), a3, min2f(a4, acc[15], t0), t0);
-                    if (__builtin_amdgcn_ballot_w64(m1 < thr[qb] + margin[qb]) == 0) continue;
-                }
+                // Skip test: minima of five groups of the 16 main-product values ({0-2}, {3-5}, {6-8},
+                // {9-11}, {12-15}).  A value can only become a hit after correction if its main value is
+                // below thr + margin, so the same five minima later tell which groups to look at.
+                const float t0 = first_read(acc[0]);
+                float g[5];
+                g[0] = min3f(t0, acc[1], acc[2], t0);
+                g[1] = min3f(acc[3], acc[4], acc[5], t0);
+                g[2] = min3f(acc[6], acc[7], acc[8], t0);
+                g[3] = min3f(acc[9], acc[10], acc[11], t0);
+                g[4] = min2f(min3f(acc[12], acc[13], acc[14], t0), acc[15], t0);
+                const float m1 = min3f(min3f(g[0], g[1], g[2], t0), g[3], g[4], t0);
+                const float loose = thr[qb] + margin[qb];
+                if (__builtin_amdgcn_ballot_w64(m1 < loose) == 0) continue;
                 __builtin_amdgcn_s_setprio(1);
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
                 __builtin_amdgcn_s_setprio(0);
                 const unsigned qlane = qwave + qb * (kQueueCap * 512);
-                // 4 x 4 hierarchy of lane-local minima: 10 VALU for 16 values
-                float g[4];
-                const float u0 = first_read(acc[0]);
-                g[0] = min2f(min3f(u0, acc[1], acc[2], u0), acc[3], u0);
+                // (take_hit's compare is compiler-visible: it is the hazard-padded first reader of the
+                // corrected accumulator)
 #pragma unroll
-                for (int k = 1; k < 4; ++k)
-                    g[k] = min2f(min3f(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], u0), acc[4 * k + 3], u0);
-                const float mn = min2f(min3f(g[0], g[1], g[2], u0), g[3]);
-                if (__builtin_amdgcn_ballot_w64(mn < thr[qb]) != 0) {
+                for (int k = 0; k < 5; ++k) {
+                    if (__builtin_amdgcn_ballot_w64(g[k] < loose) != 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (__builtin_amdgcn_ballot_w64(g[k] < thr[qb]) != 0) {
-#pragma unroll
-                            for (int r = 4 * k; r < 4 * k + 4; ++r)
-                                take_hit<M>(acc[r], id_base + acc_row(r, 0), vals[qb], idxs[qb], thr[qb], cnt[qb], qlane);
-                        }
+                        for (int r = 3 * k; r < (k == 4 ? 16 : 3 * k + 3); ++r)
+                            take_hit<M>(acc[r], id_base + acc_row(r, 0), vals[qb], idxs[qb], thr[qb], cnt[qb], qlane);
                     }
-                    if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0)
-                        flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qlane);
                 }
+                if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0)
+                    flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qlane);
             }
         }
         __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
