@@ -17,6 +17,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "coarse.hip.h"
@@ -156,6 +157,18 @@ struct sknnr_index {
     DevBuf<long long> fail_total;  // running count of certificate failures (device)
     DevBuf<long> idx_stage;
 
+    // host-buffer pipeline: pinned staging + device staging, two slots; three streams
+    struct HostSlot {
+        double* pin_x = nullptr;  size_t pin_x_n = 0;
+        double* pin_d = nullptr;  size_t pin_d_n = 0;
+        long* pin_i = nullptr;    size_t pin_i_n = 0;
+        double* pin_p = nullptr;  size_t pin_p_n = 0;
+        DevBuf<double> dev_x, dev_d, dev_p;
+        DevBuf<long> dev_i;
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
+    } slot[2];
+    hipStream_t st_h2d = nullptr, st_run = nullptr, st_d2h = nullptr;
+
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
     sknnr_stats stats{};
     bool timing_pending = false;
@@ -175,6 +188,15 @@ struct sknnr_index {
         fail_count.release();
         fail_total.release();
         idx_stage.release();
+        for (auto& sl : slot) {
+            for (void* hp : {(void*)sl.pin_x, (void*)sl.pin_d, (void*)sl.pin_i, (void*)sl.pin_p})
+                if (hp) (void)hipHostFree(hp);
+            sl.dev_x.release(); sl.dev_d.release(); sl.dev_p.release(); sl.dev_i.release();
+            for (hipEvent_t e : {sl.ev_h2d, sl.ev_done, sl.ev_d2h})
+                if (e) (void)hipEventDestroy(e);
+        }
+        for (hipStream_t h : {st_h2d, st_run, st_d2h})
+            if (h) (void)hipStreamDestroy(h);
         for (hipEvent_t e : {ev_call0, ev_call1, ev_c0, ev_c1})
             if (e) (void)hipEventDestroy(e);
         for (auto& pr : coarse_events) {
@@ -767,6 +789,149 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
 }  // namespace
 
 // ----------------------------------------------------------------------------------------
+// host-buffer pipeline
+// ----------------------------------------------------------------------------------------
+static int launch_predict(sknnr_index* ix, const double* dist, const long* idx, const double* w, long nq, int k,
+                          int mode, double* out, hipStream_t st);
+
+namespace {
+
+constexpr long kHostChunkRows = 1L << 20;  // rows per pipeline slot (SKNNR_HOST_CHUNK_ROWS overrides)
+
+long host_chunk_rows() {
+    static const long v = [] {
+        const char* e = std::getenv("SKNNR_HOST_CHUNK_ROWS");
+        const long r = e ? std::atol(e) : 0;
+        return r >= 1024 ? r : kHostChunkRows;
+    }();
+    return v;
+}
+
+// memcpy split over a few threads: a single core copies ~10 GB/s, PCIe Gen5 x16 moves ~50
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const size_t kMin = 8u << 20;
+    unsigned n = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (bytes < 2 * kMin) n = 1;
+    if (n == 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / n) + 4095) & ~(size_t)4095;
+    for (unsigned i = 0; i < n; ++i) {
+        const size_t a = (size_t)i * per;
+        if (a >= bytes) break;
+        const size_t len = std::min(per, bytes - a);
+        th.emplace_back([=] { std::memcpy((char*)dst + a, (const char*)src + a, len); });
+    }
+    for (auto& t : th) t.join();
+}
+
+template <typename T>
+int ensure_pinned(T*& p, size_t& have, size_t want) {
+    if (p && have >= want) return SKNNR_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    have = 0;
+    HIP_TRY(hipHostMalloc((void**)&p, std::max<size_t>(want, 1) * sizeof(T), hipHostMallocDefault));
+    have = want;
+    return SKNNR_OK;
+}
+
+// Pageable host arrays in, pageable host arrays out, through two pinned/device slots:
+//   host thread : copy chunk c into pinned[c&1]            | copy results of chunk c-1 out
+//   st_h2d      : pinned -> device                          (PCIe)
+//   st_run      : prep / pre-filter / finalise / scan [+ predict]
+//   st_d2h      : device -> pinned                          (PCIe)
+// so that PCIe in, kernels and PCIe out of neighbouring chunks overlap.
+int run_host_pipeline_impl(sknnr_index* ix, const double* q, long nq, const sknnr_query_opts* o, double* out_dist,
+                           long* out_idx, double* out_pred /* or null */) {
+    const int k = o->n_neighbors, t = ix->t;
+    const int d_x = o->apply_affine ? ix->d_in : ix->d;
+    const long cap = std::min(host_chunk_rows(), nq);
+    if (!ix->st_h2d) {
+        HIP_TRY(hipStreamCreateWithFlags(&ix->st_h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ix->st_run, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ix->st_d2h, hipStreamNonBlocking));
+        for (auto& sl : ix->slot) {
+            HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sl.ev_d2h, hipEventDisableTiming));
+        }
+    }
+    const int n_slots = nq > cap ? 2 : 1;
+    for (int b = 0; b < n_slots; ++b) {
+        auto& sl = ix->slot[b];
+        int rc;
+        if ((rc = ensure_pinned(sl.pin_x, sl.pin_x_n, (size_t)cap * d_x))) return rc;
+        if (out_idx && (rc = ensure_pinned(sl.pin_i, sl.pin_i_n, (size_t)cap * k))) return rc;
+        if (out_dist && (rc = ensure_pinned(sl.pin_d, sl.pin_d_n, (size_t)cap * k))) return rc;
+        if (out_pred && (rc = ensure_pinned(sl.pin_p, sl.pin_p_n, (size_t)cap * t))) return rc;
+        HIP_TRY(sl.dev_x.ensure((size_t)cap * d_x));
+        HIP_TRY(sl.dev_i.ensure((size_t)cap * k));
+        HIP_TRY(sl.dev_d.ensure((size_t)cap * k));
+        if (out_pred) HIP_TRY(sl.dev_p.ensure((size_t)cap * t));
+    }
+    struct Pending { long c0 = -1, n = 0; } pending[2];
+    auto drain = [&](int b) -> int {  // copy slot b's finished results to the caller's arrays
+        if (pending[b].c0 < 0) return SKNNR_OK;
+        auto& sl = ix->slot[b];
+        HIP_TRY(hipEventSynchronize(sl.ev_d2h));
+        const long c0 = pending[b].c0, n = pending[b].n;
+        if (out_idx) parallel_copy(out_idx + c0 * k, sl.pin_i, (size_t)n * k * sizeof(long));
+        if (out_dist) parallel_copy(out_dist + c0 * k, sl.pin_d, (size_t)n * k * sizeof(double));
+        if (out_pred) parallel_copy(out_pred + c0 * t, sl.pin_p, (size_t)n * t * sizeof(double));
+        pending[b].c0 = -1;
+        return SKNNR_OK;
+    };
+    int slot_of = 0;
+    for (long c0 = 0; c0 < nq; c0 += cap, slot_of ^= 1) {
+        const int b = slot_of;
+        const long n = std::min(cap, nq - c0);
+        auto& sl = ix->slot[b];
+        int rc = drain(b);  // the slot's previous chunk must have left before its buffers are reused
+        if (rc) return rc;
+        parallel_copy(sl.pin_x, q + c0 * d_x, (size_t)n * d_x * sizeof(double));
+        HIP_TRY(hipMemcpyAsync(sl.dev_x.p, sl.pin_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, ix->st_h2d));
+        HIP_TRY(hipEventRecord(sl.ev_h2d, ix->st_h2d));
+        HIP_TRY(hipStreamWaitEvent(ix->st_run, sl.ev_h2d, 0));
+        sknnr_query_opts oc = *o;
+        oc.row_offset = o->row_offset + c0;
+        rc = run_device(ix, sl.dev_x.p, n, &oc, sl.dev_d.p, sl.dev_i.p, ix->st_run);
+        if (rc) return rc;
+        if (out_pred) {
+            rc = launch_predict(ix, sl.dev_d.p, sl.dev_i.p, nullptr, n, k, o->weight_mode, sl.dev_p.p, ix->st_run);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipEventRecord(sl.ev_done, ix->st_run));
+        HIP_TRY(hipStreamWaitEvent(ix->st_d2h, sl.ev_done, 0));
+        if (out_idx)
+            HIP_TRY(hipMemcpyAsync(sl.pin_i, sl.dev_i.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, ix->st_d2h));
+        if (out_dist)
+            HIP_TRY(hipMemcpyAsync(sl.pin_d, sl.dev_d.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ix->st_d2h));
+        if (out_pred)
+            HIP_TRY(hipMemcpyAsync(sl.pin_p, sl.dev_p.p, (size_t)n * t * sizeof(double), hipMemcpyDeviceToHost, ix->st_d2h));
+        HIP_TRY(hipEventRecord(sl.ev_d2h, ix->st_d2h));
+        pending[b].c0 = c0;
+        pending[b].n = n;
+    }
+    for (int b = 0; b < 2; ++b) {
+        int rc = drain(b);
+        if (rc) return rc;
+    }
+    return SKNNR_OK;
+}
+
+int run_host_pipeline(sknnr_index* ix, const double* q, long nq, const sknnr_query_opts* o, double* out_dist,
+                      long* out_idx, double* out_pred) {
+    const int rc = run_host_pipeline_impl(ix, q, nq, o, out_dist, out_idx, out_pred);
+    if (rc) (void)hipDeviceSynchronize();  // nothing of a failed call may still be in flight on the slots
+    return rc;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
 // kneighbors
 // ----------------------------------------------------------------------------------------
 extern "C" int sknnr_kneighbors(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o,
@@ -780,9 +945,10 @@ extern "C" int sknnr_kneighbors(sknnr_index* ix, const double* q, int64_t nq, co
         return run_device(ix, q, nq, o, out_dist, (long*)out_idx, (hipStream_t)stream);
     }
     if (mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
-    // host buffers: stage chunk by chunk through device buffers on the default stream
+    if (q) return run_host_pipeline(ix, q, nq, o, out_dist, (long*)out_idx, nullptr);
+    // X=None: the query rows are already on the device; only the results travel
     hipStream_t st = nullptr;
-    const int d_x = (o->apply_affine && q) ? ix->d_in : ix->d;
+    const int d_x = ix->d;
     for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
         const long n = std::min<long>(kChunkRows, nq - c0);
         const double* xdev = nullptr;
@@ -904,8 +1070,9 @@ extern "C" int sknnr_predict(sknnr_index* ix, const double* q, int64_t nq, const
         return launch_predict(ix, dd, di, nullptr, nq, k, o->weight_mode, out_pred, st);
     }
     if (mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    if (q) return run_host_pipeline(ix, q, nq, o, out_dist, (long*)out_idx, out_pred);
     hipStream_t st = nullptr;
-    const int d_x = (o->apply_affine && q) ? ix->d_in : ix->d;
+    const int d_x = ix->d;
     for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
         const long n = std::min<long>(kChunkRows, nq - c0);
         const double* xdev = nullptr;

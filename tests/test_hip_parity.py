@@ -370,6 +370,46 @@ def test_chunk_boundaries_and_row_offsets_in_one_big_call(N, O):
     eng.close()
 
 
+def test_host_buffer_pipeline_matches_device_path(N, O):
+    """numpy in / numpy out goes through the pinned two-slot pipeline (1,048,576 rows per slot):
+    five slots' worth of rows, with and without distances / neighbours, must equal the
+    device-resident call bit for bit, and the oracle around the slot boundaries."""
+    import torch
+
+    from sknnr_amd._engine import KNNEngine
+
+    n_ref, d, t, k = 2500, 6, 3, 4
+    slot = 1 << 20
+    nq = 4 * slot + 12345
+    x_ref, y, _ = _synth(n_ref, 10, d, t=t)
+    rng = np.random.default_rng(11)
+    xq = x_ref[rng.integers(0, n_ref, nq)] + 0.05 * rng.standard_normal((nq, d))
+    ix = N.Index(x_ref, y)
+    o = ix.make_opts(k, weight_mode=1)
+    dist, idx = ix.kneighbors_host(xq, o)
+    _, idx_only = ix.kneighbors_host(xq, o, return_distance=False)
+    pred, dist_p, idx_p = ix.predict_host(xq, o, return_neighbors=True)
+    pred_only = ix.predict_host(xq, o)
+    np.testing.assert_array_equal(idx, idx_only)
+    np.testing.assert_array_equal(idx, idx_p)
+    np.testing.assert_array_equal(dist, dist_p)
+    np.testing.assert_array_equal(pred, pred_only)
+    eng = KNNEngine(x_ref, y)
+    xd = torch.as_tensor(xq, device="cuda")
+    dd, di = eng.kneighbors(xd, k)
+    np.testing.assert_array_equal(di.cpu().numpy(), idx)
+    np.testing.assert_array_equal(dd.cpu().numpy(), dist)
+    pd_ = eng.predict(xd, k, weights="distance")
+    np.testing.assert_array_equal(pd_.cpu().numpy(), pred)
+    for a, b in ((0, 500), (slot - 300, slot + 300), (4 * slot - 300, 4 * slot + 300), (nq - 500, nq)):
+        od, oi = O.kneighbors(x_ref, xq[a:b], k, "expanded", row_offset=a)
+        np.testing.assert_array_equal(idx[a:b], oi)
+        np.testing.assert_array_equal(dist[a:b], od)
+        np.testing.assert_allclose(pred[a:b], O.predict(y, od, oi, "distance"), rtol=1e-12, atol=0)
+    ix.close()
+    eng.close()
+
+
 def test_two_indexes_alive_and_reused(N, O):
     """Handles are independent and reusable across calls of different shapes."""
     a_ref, a_y, a_q = _synth(900, 300, 12)
