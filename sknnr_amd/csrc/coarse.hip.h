@@ -99,6 +99,19 @@ __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], fl
 // [entry][lane] so that the batched flush reads conflict-free.  A hit is appended with a
 // handful of instructions; the 44-instruction sorted insertion runs later, for all lanes of
 // the wave at once (the flush), instead of once per hit with one or two lanes active.
+// Development aid (-DSKNNR_COARSE_COUNTERS): event counts of the sweep, summed over waves into
+// coarse_counters[]; read back by sknnr_get_stats and printed to stderr.  Off in the product build.
+#ifdef SKNNR_COARSE_COUNTERS
+__device__ unsigned long long coarse_counters[16];
+#define CTR_ARG , unsigned (&ctr)[16]
+#define CTR_PASS , ctr
+#define CTR(i, n) ctr[i] += (unsigned)(n)
+#else
+#define CTR_ARG
+#define CTR_PASS
+#define CTR(i, n) ((void)0)
+#endif
+
 constexpr int kQueueCap = 4;
 constexpr int kQueueFlushAt = 3;
 __host__ __device__ constexpr int queue_bytes_per_wave(int nqb) { return nqb * kQueueCap * 64 * 8; }
@@ -169,15 +182,18 @@ __device__ __forceinline__ unsigned long long queue_load(unsigned addr) {
 // One hit: append to the lane's queue, or -- queue full -- insert directly.
 template <int M>
 __device__ __forceinline__ void take_hit(float v, int id, float (&vals)[M], int (&idxs)[M], float& thr,
-                                         int& cnt, unsigned qlane) {
+                                         int& cnt, unsigned qlane CTR_ARG) {
     const bool hit = v < thr;
     if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
+    CTR(3, 1);
+    CTR(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(hit)));
     const bool room = cnt < kQueueCap;
     if (hit && room) {
         queue_store(qlane + cnt * 512, v, id);
         cnt += 1;
     }
     if (__builtin_amdgcn_ballot_w64(hit && !room) != 0) {
+        CTR(5, 1);
         if (hit && !room) {
             list_insert<M>(vals, idxs, v, id);
             thr = min2f(thr, vals[M - 1]);
@@ -185,24 +201,41 @@ __device__ __forceinline__ void take_hit(float v, int id, float (&vals)[M], int 
     }
 }
 
+// The M-th smallest entry of the union of the two sorted M-lists owned by lanes l and l+32
+// (the two lanes that share a query): max_i min(a_i, b_{M-1-i}).  Both lanes get the same value.
+template <int M>
+__device__ __forceinline__ float pair_union_rank_m(const float (&vals)[M]) {
+    float other[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) other[i] = __shfl_xor(vals[i], 32, 64);
+    float u = fminf(vals[0], other[M - 1]);
+#pragma unroll
+    for (int i = 1; i < M; ++i) u = fmaxf(u, fminf(vals[i], other[M - 1 - i]));
+    return u;
+}
+
 // Batched insertion of every lane's queued candidates, then the threshold of the two lanes
-// that own the same query (l and l+32) is tightened to the smaller of their list maxima:
-// everything either lane rejects from now on is >= that value, which is what the
-// finaliser's certificate assumes (min over the two lists' last entries).
+// that own the same query (l and l+32) is tightened to the M-th smallest entry of their two
+// lists together.  The lower lane's list starts with M - J sentinels (-FLT_MAX), so that entry
+// is the J-th best value the query has seen (J = neighbours searched + 1): everything either
+// lane rejects from now on is >= that value, which is the bound the finaliser's certificate
+// recomputes from the stored lists.
 template <int M>
 __device__ __forceinline__ void flush_queue(float (&vals)[M], int (&idxs)[M], float& thr, int& cnt,
-                                            unsigned qlane) {
+                                            unsigned qlane CTR_ARG) {
     for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0; ++i) {
+        CTR(7, 1);
+        CTR(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < cnt)));
         if (i < cnt) {
             const unsigned long long e = queue_load(qlane + i * 512);
             const float ev = __uint_as_float((unsigned)e);
+            CTR(9, __builtin_amdgcn_ballot_w64(ev < vals[M - 1]) != 0);
+            CTR(10, __builtin_popcountll(__builtin_amdgcn_ballot_w64(ev < vals[M - 1])));
             if (ev < vals[M - 1]) list_insert<M>(vals, idxs, ev, (int)(e >> 32));
         }
     }
     cnt = 0;
-    const float own = vals[M - 1];
-    const float other = __shfl_xor(own, 32, 64);
-    thr = min2f(own, other);
+    thr = pair_union_rank_m<M>(vals);
 }
 
 // KS : 16-wide K-steps per split part (padded feature count / 16)
@@ -214,6 +247,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
               const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments
               const double* __restrict__ qnc,  // [n_qblocks*32] |q'|^2 (0 for padding rows)
               float skip_scale,                // 2^-9 * max|r'| * (1 + slack): margin = skip_scale * |q'|
+              int n_sentinel,                  // M - (neighbours searched + 1): leading sentinels of the lower lane's list
               float* __restrict__ cand_val,    // [n_qblocks*32][2][M]
               int* __restrict__ cand_idx) {
     constexpr int TPS = tiles_per_stage(KS);
@@ -254,11 +288,14 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
         margin[qb] = skip_scale * (float)sqrt(qnc[(size_t)(qb0 + qb) * 32 + (lane & 31)]) + 1e-30f;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            vals[qb][i] = FLT_MAX;
+            vals[qb][i] = (half == 0 && i < n_sentinel) ? -FLT_MAX : FLT_MAX;
             idxs[qb][i] = -1;
         }
     }
 
+#ifdef SKNNR_COARSE_COUNTERS
+    unsigned ctr[16] = {};
+#endif
     stage_copy(rimg, smem, STAGE, wave, lane, WAVES);
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
 
@@ -307,7 +344,11 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 g[4] = min2f(min3f(acc[12], acc[13], acc[14], t0), acc[15], t0);
                 const float m1 = min3f(min3f(g[0], g[1], g[2], t0), g[3], g[4], t0);
                 const float loose = thr[qb] + margin[qb];
+                CTR(0, 1);
                 if (__builtin_amdgcn_ballot_w64(m1 < loose) == 0) continue;
+                CTR(1, 1);
+                CTR(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(m1 < loose)));
+                CTR(12, __builtin_amdgcn_ballot_w64(m1 < thr[qb]) != 0);
                 __builtin_amdgcn_s_setprio(1);
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
                 __builtin_amdgcn_s_setprio(0);
@@ -317,13 +358,16 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     if (__builtin_amdgcn_ballot_w64(g[k] < loose) != 0) {
+                        CTR(2, 1);
 #pragma unroll
                         for (int r = 3 * k; r < (k == 4 ? 16 : 3 * k + 3); ++r)
-                            take_hit<M>(acc[r], id_base + acc_row(r, 0), vals[qb], idxs[qb], thr[qb], cnt[qb], qlane);
+                            take_hit<M>(acc[r], id_base + acc_row(r, 0), vals[qb], idxs[qb], thr[qb], cnt[qb], qlane CTR_PASS);
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0)
-                    flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qlane);
+                if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) {
+                    CTR(6, 1);
+                    flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qlane CTR_PASS);
+                }
             }
         }
         __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
@@ -331,7 +375,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-        flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qwave + qb * (kQueueCap * 512));
+        flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qwave + qb * (kQueueCap * 512) CTR_PASS);
         const size_t q = (size_t)(qb0 + qb) * 32 + (lane & 31);
         const size_t base = (q * 2 + half) * M;
 #pragma unroll
@@ -340,6 +384,10 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
             cand_idx[base + i] = idxs[qb][i];
         }
     }
+#ifdef SKNNR_COARSE_COUNTERS
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&coarse_counters[i], (unsigned long long)ctr[i]);
+#endif
 }
 
 // Diagnostic twin of the production kernel: the same split contraction, every value

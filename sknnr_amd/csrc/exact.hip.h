@@ -367,8 +367,14 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 
     // certificate: every reference outside the lists has a float64 d2 above tau
     const double tau = group_min<LPQ>(rank >= s.kk - 1 ? d2 : INFINITY);
-    const float t_last = (slot == a.m_list - 1) ? (valid ? cv : INFINITY) : INFINITY;
-    const double t_min = group_min<LPQ>((double)t_last);
+    // Bound on everything outside the lists: the m_list-th smallest entry of the two lists together
+    // (sentinels included), max_i min(a_i, b_{m-1-i}) -- the value the pre-filter's rejections were
+    // tested against last (coarse.hip.h, pair_union_rank_m).
+    const float cv_raw = has_slot ? cv : INFINITY;
+    const int partner = M + (has_slot ? a.m_list - 1 - slot : 0);
+    const float cv_partner = __shfl(cv_raw, partner, LPQ);
+    const double t_pair = (list == 0 && has_slot) ? (double)fminf(cv_raw, cv_partner) : -INFINITY;
+    const double t_min = group_max<LPQ>(t_pair);
     const double bound = (qn + t_min - eps) * a.inv_s2;
     bool certified = (n_usable >= s.kk) && (tau < INFINITY) && (bound > tau);
     // Exactly tied float64 distances: which tied row the reference keeps at the k-th slot (and,
@@ -526,159 +532,230 @@ __device__ void dual_quicksort_ref(double* v0, int* x0, int n0, int* stack) {
     }
 }
 
-// Workgroup LDS: xs[d] | hv[KK] | hi[KK] | stack[2*KK+4] | d2[2][256]
-__host__ __device__ inline size_t scan_block_bytes(int d, int kk) {
-    size_t b = 8 * (size_t)((d + 1) & ~1) + 8 * (size_t)kk + 4 * (size_t)(kk + (kk & 1));
-    b += 4 * (size_t)((2 * kk + 4 + 1) & ~1);
-    b = (b + 15) & ~(size_t)15;
-    return b + 2 * 256 * 8;
-}
-
 constexpr int kScanWaves = 4;
+constexpr int kScanQPW = 2;                          // queries whose heaps one wave replays
+constexpr int kScanNQ = kScanWaves * kScanQPW;       // queries per workgroup pass
+constexpr int kScanRefs = 2 * kScanWaves * 64;       // references per step: two per thread
 
-// One workgroup (4 waves) per query.  Per step of 256 references every lane evaluates ONE float64
-// distance (column j of the transposed copy: coalesced; up to 32 features loaded at once so a
-// step is a single memory round trip), the 256 values go to LDS, and after the workgroup barrier
-// wave 0 offers them to the heap in index order while the other waves already work on the next
-// step (two LDS buffers; wave 0 has finished replaying step s-1 before it arrives at barrier s).
+// Workgroup LDS: xs[NQ][dpad] | qn[NQ] | hv[NQ][KK] | hi[NQ][kkp] | stack[NQ][stk] | d2[NQ][kScanRefs]
+struct ScanLayout {
+    int dpad, kkp, stk;
+    size_t xs, qn, hv, hi, stack, d2, total;
+};
+__host__ __device__ inline ScanLayout scan_layout(int d, int kk) {
+    ScanLayout L;
+    L.dpad = (d + 1) & ~1;
+    L.kkp = kk + (kk & 1);
+    L.stk = (2 * kk + 4 + 1) & ~1;
+    size_t b = 0;
+    L.xs = b;    b += 8 * (size_t)kScanNQ * L.dpad;
+    L.qn = b;    b += 8 * (size_t)kScanNQ;
+    L.hv = b;    b += 8 * (size_t)kScanNQ * kk;
+    L.hi = b;    b += 4 * (size_t)kScanNQ * L.kkp;
+    L.stack = b; b += 4 * (size_t)kScanNQ * L.stk;
+    b = (b + 15) & ~(size_t)15;
+    L.d2 = b;    b += 8 * (size_t)kScanNQ * kScanRefs;
+    L.total = b;
+    return L;
+}
+__host__ __device__ inline size_t scan_block_bytes(int d, int kk) { return scan_layout(d, kk).total; }
+
+// One workgroup (4 waves) per pass of kScanNQ queries.  Per step of 512 references every thread
+// loads TWO columns of the transposed copy (coalesced) once and evaluates their float64 distances to
+// all eight queries (query values are LDS broadcasts, each feeding two fma chains), so a query
+// costs 1/8 of a sweep over the reference copy; the 8 x 512 values go to LDS and every wave then
+// offers them, in index order, to the heaps of its own two queries.  Each distance is the same
+// ascending-feature fma chain as before: results do not depend on the grouping.
+template <int FORMULA>
 __global__ void __launch_bounds__(kScanWaves * 64) exact_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NT = kScanWaves * 64;
+    constexpr int NQ = kScanNQ;
     const SelectArgs& s = a.s;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int KK = s.kk;
-    double* xs = (double*)smem_raw;
-    double* hv = xs + ((s.d + 1) & ~1);
-    int* hi = (int*)(hv + KK);
-    int* stack = hi + KK + (KK & 1);
-    double* d2buf = (double*)(smem_raw + scan_block_bytes(s.d, KK) - 2 * 256 * 8);
+    const int d = s.d;
+    const ScanLayout L = scan_layout(d, KK);
+    double* xs = (double*)(smem_raw + L.xs);
+    double* qns = (double*)(smem_raw + L.qn);
+    double* hv_all = (double*)(smem_raw + L.hv);
+    int* hi_all = (int*)(smem_raw + L.hi);
+    int* stack_all = (int*)(smem_raw + L.stack);
+    double* d2buf = (double*)(smem_raw + L.d2);
 
     const long n_items = a.list ? (long)*a.count : s.nq;
-    for (long f = blockIdx.x; f < n_items; f += gridDim.x) {
-        const long q = a.list ? (long)a.list[f] : f;
-        __syncthreads();  // previous query's LDS state is dead
-        for (int c = tid; c < s.d; c += kScanWaves * 64) xs[c] = s.xq[q * s.d + c];
-        for (int i = tid; i < KK; i += kScanWaves * 64) {
-            hv[i] = DBL_MAX;
-            hi[i] = 0;
+    for (long f0 = (long)blockIdx.x * NQ; f0 < n_items; f0 += (long)gridDim.x * NQ) {
+        const int n_here = (int)((n_items - f0) < NQ ? (n_items - f0) : NQ);
+        __syncthreads();  // previous pass's LDS state is dead
+        // padding slots repeat the pass's last query; nothing is written for them
+        for (int e = tid; e < NQ * d; e += NT) {
+            const int qi = e / d, c = e - qi * d;
+            const long fi = f0 + (qi < n_here ? qi : n_here - 1);
+            const long q = a.list ? (long)a.list[fi] : fi;
+            xs[qi * L.dpad + c] = s.xq[q * d + c];
+        }
+        for (int i = tid; i < NQ * KK; i += NT) {
+            const int qi = i / KK, e = i - qi * KK;
+            hv_all[qi * KK + e] = DBL_MAX;
+            hi_all[qi * L.kkp + e] = 0;
         }
         __syncthreads();
-        double qn = 0.0;
-        if (s.formula == 0)
-            for (int c = 0; c < s.d; ++c) qn = fma(xs[c], xs[c], qn);
-        double root = DBL_MAX;  // meaningful in wave 0 only
+        if (FORMULA == 0 && tid < NQ) {
+            double qn = 0.0;
+            for (int c = 0; c < d; ++c) qn = fma(xs[tid * L.dpad + c], xs[tid * L.dpad + c], qn);
+            qns[tid] = qn;
+        }
+        double root[kScanQPW];
+#pragma unroll
+        for (int i = 0; i < kScanQPW; ++i) root[i] = DBL_MAX;
 
         const size_t ld = (size_t)s.n_ref;
-        int step = 0;
-        for (int j0 = 0; j0 < s.n_ref; j0 += 256, ++step) {
-            const int j = j0 + tid;
-            const double* col = a.refT + (j < s.n_ref ? j : 0);
-            double acc = 0.0;
+        for (int j0 = 0; j0 < s.n_ref; j0 += kScanRefs) {
+            const int ja = j0 + tid, jb = j0 + NT + tid;
+            const double* cola = a.refT + (ja < s.n_ref ? ja : 0);
+            const double* colb = a.refT + (jb < s.n_ref ? jb : 0);
+            double acc[NQ][2];
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) acc[qi][0] = acc[qi][1] = 0.0;
             int c = 0;
-            for (; c + 32 <= s.d; c += 32) {
-                double r[32];
-#pragma unroll
-                for (int w = 0; w < 32; ++w) r[w] = col[(size_t)(c + w) * ld];
-#pragma unroll
-                for (int w = 0; w < 32; ++w) {
-                    if (s.formula == 0) acc = fma(xs[c + w], r[w], acc);
-                    else { const double t = xs[c + w] - r[w]; acc = acc + t * t; }
-                }
-            }
-            for (; c + 8 <= s.d; c += 8) {
-                double r[8];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) r[w] = col[(size_t)(c + w) * ld];
+            for (; c + 8 <= d; c += 8) {
+                double ra[8], rb[8];
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
-                    if (s.formula == 0) acc = fma(xs[c + w], r[w], acc);
-                    else { const double t = xs[c + w] - r[w]; acc = acc + t * t; }
+                    ra[w] = cola[(size_t)(c + w) * ld];
+                    rb[w] = colb[(size_t)(c + w) * ld];
                 }
-            }
-            for (; c < s.d; ++c) {
-                const double rv = col[(size_t)c * ld];
-                if (s.formula == 0) acc = fma(xs[c], rv, acc);
-                else { const double t = xs[c] - rv; acc = acc + t * t; }
-            }
-            double d2 = INFINITY;
-            if (j < s.n_ref) {
-                if (s.formula == 0) {
-                    d2 = qn + (-2.0 * acc) + s.rn[j];
-                    d2 = d2 > 0.0 ? d2 : 0.0;
-                } else {
-                    d2 = acc;
-                }
-            }
-            double* buf = d2buf + (step & 1) * 256;
-            buf[tid] = d2;
-            __syncthreads();
-            if (wave == 0) {
-#pragma unroll 1
-                for (int u = 0; u < 4; ++u) {
-                    const double v64 = buf[64 * u + lane];
-                    unsigned long long m = __builtin_amdgcn_ballot_w64(v64 < root);
-                    while (m) {
-                        const int bit = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const double v = __shfl(v64, bit, 64);
-                        if (v < root) {  // the root may have dropped since the ballot
-                            if (lane == 0) heap_push_ref(hv, hi, KK, v, j0 + 64 * u + bit);
-                            __builtin_amdgcn_wave_barrier();
-                            root = hv[0];
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        const double x = xs[qi * L.dpad + c + w];
+                        if (FORMULA == 0) {
+                            acc[qi][0] = fma(x, ra[w], acc[qi][0]);
+                            acc[qi][1] = fma(x, rb[w], acc[qi][1]);
+                        } else {
+                            const double ta = x - ra[w], tb = x - rb[w];
+                            acc[qi][0] = acc[qi][0] + ta * ta;
+                            acc[qi][1] = acc[qi][1] + tb * tb;
                         }
                     }
                 }
             }
-        }
-
-        if (tid == 0) {
-            dual_quicksort_ref(hv, hi, KK, stack);
-            // drop self (X=None), sqrt, reorder: serial over <= KK entries
-            const long self_id = s.row_offset + q;
-            int drop = -1;
-            if (s.exclude_self) {
-                drop = 0;
-                for (int i = 0; i < KK; ++i)
-                    if ((long)hi[i] == self_id) { drop = i; break; }
-            }
-            int n = 0;
-            for (int i = 0; i < KK; ++i) {
-                if (i == drop) continue;
-                hv[n] = sqrt(hv[i] > 0.0 ? hv[i] : 0.0);
-                hi[n] = hi[i];
-                ++n;
-            }
-            if (n > s.k) n = s.k;
-            if (s.deterministic) {
-                double dmax = 0.0;
-                for (int i = 0; i < n; ++i) dmax = fmax(dmax, hv[i]);
-                const double row_scale = fmax(dmax, 1.0);
-                // stable insertion sort by (rounded, |idx - row|, idx)  (REF _base.py:166-175)
-                for (int i = 1; i < n; ++i) {
-                    const double dv = hv[i];
-                    const int iv = hi[i];
-                    const double k0 = round_key(dv / row_scale, s.pow10, s.pow10_is_divisor);
-                    long k1 = (long)iv - self_id;
-                    k1 = k1 < 0 ? -k1 : k1;
-                    int jj = i - 1;
-                    while (jj >= 0) {
-                        const double k0j = round_key(hv[jj] / row_scale, s.pow10, s.pow10_is_divisor);
-                        long k1j = (long)hi[jj] - self_id;
-                        k1j = k1j < 0 ? -k1j : k1j;
-                        const bool greater = (k0j > k0) || (k0j == k0 && (k1j > k1 || (k1j == k1 && hi[jj] > iv)));
-                        if (!greater) break;
-                        hv[jj + 1] = hv[jj];
-                        hi[jj + 1] = hi[jj];
-                        --jj;
+            for (; c < d; ++c) {
+                const double rav = cola[(size_t)c * ld], rbv = colb[(size_t)c * ld];
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    const double x = xs[qi * L.dpad + c];
+                    if (FORMULA == 0) {
+                        acc[qi][0] = fma(x, rav, acc[qi][0]);
+                        acc[qi][1] = fma(x, rbv, acc[qi][1]);
+                    } else {
+                        const double ta = x - rav, tb = x - rbv;
+                        acc[qi][0] = acc[qi][0] + ta * ta;
+                        acc[qi][1] = acc[qi][1] + tb * tb;
                     }
-                    hv[jj + 1] = dv;
-                    hi[jj + 1] = iv;
                 }
             }
-            for (int i = 0; i < n; ++i) {
-                if (s.out_dist) s.out_dist[q * s.k + i] = hv[i];
-                s.out_idx[q * s.k + i] = hi[i];
+            const double rna = (FORMULA == 0 && ja < s.n_ref) ? s.rn[ja] : 0.0;
+            const double rnb = (FORMULA == 0 && jb < s.n_ref) ? s.rn[jb] : 0.0;
+            __syncthreads();  // the previous step's replay has finished reading d2buf (and qns is published)
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                double da = acc[qi][0], db = acc[qi][1];
+                if (FORMULA == 0) {
+                    const double qn = qns[qi];
+                    da = qn + (-2.0 * da) + rna;
+                    db = qn + (-2.0 * db) + rnb;
+                    da = da > 0.0 ? da : 0.0;
+                    db = db > 0.0 ? db : 0.0;
+                }
+                d2buf[qi * kScanRefs + tid] = ja < s.n_ref ? da : INFINITY;
+                d2buf[qi * kScanRefs + NT + tid] = jb < s.n_ref ? db : INFINITY;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int i = 0; i < kScanQPW; ++i) {
+                const int qi = wave * kScanQPW + i;
+                if (qi >= n_here) break;
+                double* hv = hv_all + qi * KK;
+                int* hi = hi_all + qi * L.kkp;
+                const double* buf = d2buf + qi * kScanRefs;
+                double rt = root[i];
+#pragma unroll 1
+                for (int u = 0; u < kScanRefs / 64; ++u) {
+                    const double v64 = buf[64 * u + lane];
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(v64 < rt);
+                    while (m) {
+                        const int bit = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const double v = __shfl(v64, bit, 64);
+                        if (v < rt) {  // the root may have dropped since the ballot
+                            if (lane == 0) heap_push_ref(hv, hi, KK, v, j0 + 64 * u + bit);
+                            __builtin_amdgcn_wave_barrier();
+                            rt = hv[0];
+                        }
+                    }
+                }
+                root[i] = rt;
+            }
+        }
+
+        if (lane == 0) {
+            for (int i = 0; i < kScanQPW; ++i) {
+                const int qi = wave * kScanQPW + i;
+                if (qi >= n_here) break;
+                const long q = a.list ? (long)a.list[f0 + qi] : f0 + qi;
+                double* hv = hv_all + qi * KK;
+                int* hi = hi_all + qi * L.kkp;
+                dual_quicksort_ref(hv, hi, KK, stack_all + qi * L.stk);
+                // drop self (X=None), sqrt, reorder: serial over <= KK entries
+                const long self_id = s.row_offset + q;
+                int drop = -1;
+                if (s.exclude_self) {
+                    drop = 0;
+                    for (int e = 0; e < KK; ++e)
+                        if ((long)hi[e] == self_id) { drop = e; break; }
+                }
+                int n = 0;
+                for (int e = 0; e < KK; ++e) {
+                    if (e == drop) continue;
+                    hv[n] = sqrt(hv[e] > 0.0 ? hv[e] : 0.0);
+                    hi[n] = hi[e];
+                    ++n;
+                }
+                if (n > s.k) n = s.k;
+                if (s.deterministic) {
+                    double dmax = 0.0;
+                    for (int e = 0; e < n; ++e) dmax = fmax(dmax, hv[e]);
+                    const double row_scale = fmax(dmax, 1.0);
+                    // stable insertion sort by (rounded, |idx - row|, idx)  (REF _base.py:166-175)
+                    for (int e = 1; e < n; ++e) {
+                        const double dv = hv[e];
+                        const int iv = hi[e];
+                        const double k0 = round_key(dv / row_scale, s.pow10, s.pow10_is_divisor);
+                        long k1 = (long)iv - self_id;
+                        k1 = k1 < 0 ? -k1 : k1;
+                        int jj = e - 1;
+                        while (jj >= 0) {
+                            const double k0j = round_key(hv[jj] / row_scale, s.pow10, s.pow10_is_divisor);
+                            long k1j = (long)hi[jj] - self_id;
+                            k1j = k1j < 0 ? -k1j : k1j;
+                            const bool greater = (k0j > k0) || (k0j == k0 && (k1j > k1 || (k1j == k1 && hi[jj] > iv)));
+                            if (!greater) break;
+                            hv[jj + 1] = hv[jj];
+                            hi[jj + 1] = hi[jj];
+                            --jj;
+                        }
+                        hv[jj + 1] = dv;
+                        hi[jj + 1] = iv;
+                    }
+                }
+                for (int e = 0; e < n; ++e) {
+                    if (s.out_dist) s.out_dist[q * s.k + e] = hv[e];
+                    s.out_idx[q * s.k + e] = hi[e];
+                }
             }
         }
     }

@@ -496,6 +496,18 @@ extern "C" int sknnr_get_stats(const sknnr_index* cix, sknnr_stats* out) {
     if (hipMemcpy(&total, ix->fail_total.p, sizeof total, hipMemcpyDeviceToHost) == hipSuccess)
         ix->stats.exact_fallbacks = total;
     *out = ix->stats;
+#ifdef SKNNR_COARSE_COUNTERS
+    {
+        unsigned long long c[16] = {};
+        (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(sknnr::coarse_counters), sizeof c);
+        static const char* names[16] = {"tile_qblocks", "visits", "group_hits", "member_hits", "hit_lanes", "overflow_inserts",
+                                        "flushes", "flush_iters", "flush_iter_lanes", "flush_insert_iters", "flush_insert_lanes",
+                                        "visit_lanes", "visits_with_true_hit", "", "", ""};
+        for (int i = 0; i < 13; ++i) std::fprintf(stderr, "[coarse] %-22s %llu\n", names[i], c[i]);
+        std::memset(c, 0, sizeof c);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(sknnr::coarse_counters), c, sizeof c);
+    }
+#endif
     return SKNNR_OK;
 }
 
@@ -563,7 +575,7 @@ int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool aff
 }
 
 template <int KS, int M>
-int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
+int launch_coarse_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
     constexpr int NQB = coarse_nqb(KS, M);
     constexpr int WAVES = coarse_waves(KS, M);
     constexpr int QPB = WAVES * NQB * 32;
@@ -575,7 +587,7 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, hipStream_t st) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(WAVES * 64), sh, st>>>(
         ix->rimg.p, ix->n_stages, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
-        ix->cand_val.p, ix->cand_idx.p);
+        M - (kk + 1), ix->cand_val.p, ix->cand_idx.p);
     HIP_TRY(hipGetLastError());
     return SKNNR_OK;
 }
@@ -586,26 +598,26 @@ constexpr int kCoarseMaxKK = 31;
 int coarse_list_len(int kk) { return kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32)); }
 
 template <int M>
-int launch_coarse_m(sknnr_index* ix, long nq_pad, hipStream_t st) {
+int launch_coarse_m(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
     switch (ix->ks) {
-        case 1: return launch_coarse_ks<1, M>(ix, nq_pad, st);
-        case 2: return launch_coarse_ks<2, M>(ix, nq_pad, st);
-        case 3: return launch_coarse_ks<3, M>(ix, nq_pad, st);
-        case 4: return launch_coarse_ks<4, M>(ix, nq_pad, st);
-        case 5: return launch_coarse_ks<5, M>(ix, nq_pad, st);
-        case 6: return launch_coarse_ks<6, M>(ix, nq_pad, st);
-        case 7: return launch_coarse_ks<7, M>(ix, nq_pad, st);
-        case 8: return launch_coarse_ks<8, M>(ix, nq_pad, st);
+        case 1: return launch_coarse_ks<1, M>(ix, nq_pad, kk, st);
+        case 2: return launch_coarse_ks<2, M>(ix, nq_pad, kk, st);
+        case 3: return launch_coarse_ks<3, M>(ix, nq_pad, kk, st);
+        case 4: return launch_coarse_ks<4, M>(ix, nq_pad, kk, st);
+        case 5: return launch_coarse_ks<5, M>(ix, nq_pad, kk, st);
+        case 6: return launch_coarse_ks<6, M>(ix, nq_pad, kk, st);
+        case 7: return launch_coarse_ks<7, M>(ix, nq_pad, kk, st);
+        case 8: return launch_coarse_ks<8, M>(ix, nq_pad, kk, st);
     }
     return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for ks = %d", ix->ks);
 }
 
-int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, hipStream_t st) {
+int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
     switch (m_list) {
-        case 6: return launch_coarse_m<6>(ix, nq_pad, st);
-        case 8: return launch_coarse_m<8>(ix, nq_pad, st);
-        case 16: return launch_coarse_m<16>(ix, nq_pad, st);
-        case 32: return launch_coarse_m<32>(ix, nq_pad, st);
+        case 6: return launch_coarse_m<6>(ix, nq_pad, kk, st);
+        case 8: return launch_coarse_m<8>(ix, nq_pad, kk, st);
+        case 16: return launch_coarse_m<16>(ix, nq_pad, kk, st);
+        case 32: return launch_coarse_m<32>(ix, nq_pad, kk, st);
     }
     return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for list length %d", m_list);
 }
@@ -627,10 +639,12 @@ int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int
     if (sh > 150 * 1024)
         return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", s.k, s.d);
     ScanArgs a{s, ix->refT.p, list, count};
-    HIP_TRY(hipFuncSetAttribute((const void*)exact_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    // one 4-wave workgroup per query at a time; 4 workgroups per CU keep the float64 pipes busy
-    const long blocks = std::max<long>(1, std::min<long>(max_items, 256L * 4));
-    exact_scan_kernel<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
+    // one 4-wave workgroup per pass of kScanNQ queries; 4 workgroups per CU keep the float64 pipes busy
+    const long passes = (max_items + kScanNQ - 1) / kScanNQ;
+    const long blocks = std::max<long>(1, std::min<long>(passes, 256L * 4));
+    auto kern = s.formula == 0 ? exact_scan_kernel<0> : exact_scan_kernel<1>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    kern<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
     HIP_TRY(hipGetLastError());
     return SKNNR_OK;
 }
@@ -743,7 +757,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         }
         auto& ev = ix->coarse_events[ix->coarse_events_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
-        int rc = launch_coarse(ix, n_pad, coarse_list_len(kk), st);
+        int rc = launch_coarse(ix, n_pad, coarse_list_len(kk), kk, st);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev.second, st));
 
