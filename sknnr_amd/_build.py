@@ -47,13 +47,15 @@ def is_stale() -> bool:
     return any(os.path.getmtime(p) > lib_m for p in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    """Compile the library if it is missing or older than its sources."""
-    if not force and not is_stale():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str | None = None) -> str:
+    """Compile the library if it is missing or older than its sources (always, for a variant
+    written to ``out_path``)."""
+    if out_path is None and not force and not is_stale():
         return LIB_PATH
+    target = out_path or LIB_PATH
     cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
+    cmd += ["-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     proc = subprocess.run(cmd, capture_output=True, text=True)
@@ -61,8 +63,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
     if verbose and proc.stderr:
         print(proc.stderr, file=sys.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":

@@ -91,7 +91,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return _build.LIB_PATH
+    """The in-tree build, or the file named by SKNNR_HIP_LIBRARY (development variants)."""
+    return os.environ.get("SKNNR_HIP_LIBRARY") or _build.LIB_PATH
 
 
 def load(build_if_missing: bool = False):

@@ -101,6 +101,9 @@ __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], fl
 // the wave at once (the flush), instead of once per hit with one or two lanes active.
 // Development aid (-DSKNNR_COARSE_COUNTERS): event counts of the sweep, summed over waves into
 // coarse_counters[]; read back by sknnr_get_stats and printed to stderr.  Off in the product build.
+#ifdef SKNNR_COARSE_TIMERS
+__device__ unsigned long long coarse_timers[8];
+#endif
 #ifdef SKNNR_COARSE_COUNTERS
 __device__ unsigned long long coarse_counters[16];
 #define CTR_ARG , unsigned (&ctr)[16]
@@ -111,6 +114,7 @@ __device__ unsigned long long coarse_counters[16];
 #define CTR_PASS
 #define CTR(i, n) ((void)0)
 #endif
+
 
 constexpr int kQueueCap = 4;
 constexpr int kQueueFlushAt = 3;
@@ -205,12 +209,9 @@ __device__ __forceinline__ void take_hit(float v, int id, float (&vals)[M], int 
 // (the two lanes that share a query): max_i min(a_i, b_{M-1-i}).  Both lanes get the same value.
 template <int M>
 __device__ __forceinline__ float pair_union_rank_m(const float (&vals)[M]) {
-    float other[M];
+    float u = fminf(vals[0], __shfl_xor(vals[M - 1], 32, 64));
 #pragma unroll
-    for (int i = 0; i < M; ++i) other[i] = __shfl_xor(vals[i], 32, 64);
-    float u = fminf(vals[0], other[M - 1]);
-#pragma unroll
-    for (int i = 1; i < M; ++i) u = fmaxf(u, fminf(vals[i], other[M - 1 - i]));
+    for (int i = 1; i < M; ++i) u = fmaxf(u, fminf(vals[i], __shfl_xor(vals[M - 1 - i], 32, 64)));
     return u;
 }
 
@@ -296,6 +297,27 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 #ifdef SKNNR_COARSE_COUNTERS
     unsigned ctr[16] = {};
 #endif
+#ifdef SKNNR_COARSE_TIMERS  // development aid: where one wave's cycles go (s_memtime stamps)
+    unsigned long long tm[8] = {};
+    unsigned long long tk = 0, tk0 = 0;
+#define TICK()                                  \
+    do {                                        \
+        asm volatile("" ::: "memory");          \
+        tk = __builtin_readcyclecounter();      \
+        asm volatile("" ::: "memory");          \
+    } while (0)
+#define TSTAMP(i)            \
+    do {                     \
+        tk0 = tk;            \
+        TICK();              \
+        tm[i] += tk - tk0;   \
+    } while (0)
+    TICK();
+    const unsigned long long t_begin = tk;
+#else
+#define TICK() ((void)0)
+#define TSTAMP(i) ((void)0)
+#endif
     stage_copy(rimg, smem, STAGE, wave, lane, WAVES);
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
 
@@ -326,6 +348,10 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 }
             }
             const int id_base = (st * TPS + t) * 32 + 4 * half;
+#ifdef SKNNR_COARSE_TIMERS
+            asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(c0));
+#endif
+            TSTAMP(0);  // tile operands landed in registers
 
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
@@ -345,7 +371,11 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 const float m1 = min3f(min3f(g[0], g[1], g[2], t0), g[3], g[4], t0);
                 const float loose = thr[qb] + margin[qb];
                 CTR(0, 1);
-                if (__builtin_amdgcn_ballot_w64(m1 < loose) == 0) continue;
+                if (__builtin_amdgcn_ballot_w64(m1 < loose) == 0) {
+                    TSTAMP(1);  // main product + skip test, no visit
+                    continue;
+                }
+                TSTAMP(2);  // main product + skip test, visit follows
                 CTR(1, 1);
                 CTR(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(m1 < loose)));
                 CTR(12, __builtin_amdgcn_ballot_w64(m1 < thr[qb]) != 0);
@@ -364,13 +394,17 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                             take_hit<M>(acc[r], id_base + acc_row(r, 0), vals[qb], idxs[qb], thr[qb], cnt[qb], qlane CTR_PASS);
                     }
                 }
+                TSTAMP(3);  // corrections + hit scan
                 if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) {
                     CTR(6, 1);
                     flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qlane CTR_PASS);
+                    TSTAMP(4);  // flush
                 }
             }
         }
+        TSTAMP(5);  // loop overhead
         __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
+        TSTAMP(6);  // barrier (+ stage issue)
     }
 
 #pragma unroll
@@ -387,6 +421,12 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 #ifdef SKNNR_COARSE_COUNTERS
     if (lane == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(&coarse_counters[i], (unsigned long long)ctr[i]);
+#endif
+#ifdef SKNNR_COARSE_TIMERS
+    TICK();
+    tm[7] = tk - t_begin;
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&coarse_timers[i], tm[i]);
 #endif
 }
 

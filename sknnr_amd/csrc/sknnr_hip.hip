@@ -496,6 +496,18 @@ extern "C" int sknnr_get_stats(const sknnr_index* cix, sknnr_stats* out) {
     if (hipMemcpy(&total, ix->fail_total.p, sizeof total, hipMemcpyDeviceToHost) == hipSuccess)
         ix->stats.exact_fallbacks = total;
     *out = ix->stats;
+#ifdef SKNNR_COARSE_TIMERS
+    {
+        unsigned long long c[8] = {};
+        (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(sknnr::coarse_timers), sizeof c);
+        static const char* names[8] = {"operands_wait", "main_no_visit", "main_then_visit", "correct_and_scan", "flush",
+                                       "loop_overhead", "barrier", "wave_total"};
+        for (int i = 0; i < 8; ++i)
+            std::fprintf(stderr, "[coarse-time] %-18s %14llu  %5.1f %%\n", names[i], c[i], 100.0 * (double)c[i] / (double)(c[7] ? c[7] : 1));
+        std::memset(c, 0, sizeof c);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(sknnr::coarse_timers), c, sizeof c);
+    }
+#endif
 #ifdef SKNNR_COARSE_COUNTERS
     {
         unsigned long long c[16] = {};
@@ -597,6 +609,12 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
 constexpr int kCoarseMaxKK = 31;
 int coarse_list_len(int kk) { return kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32)); }
 
+#ifdef SKNNR_DEV_ONLY_KS2_M6  // development builds: only the bench's instantiation (fast compile)
+int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
+    if (ix->ks == 2 && m_list == 6) return launch_coarse_ks<2, 6>(ix, nq_pad, kk, st);
+    return fail(SKNNR_ERR_UNSUPPORTED, "development build: ks = 2, list length 6 only");
+}
+#else
 template <int M>
 int launch_coarse_m(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
     switch (ix->ks) {
@@ -621,6 +639,8 @@ int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t 
     }
     return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for list length %d", m_list);
 }
+
+#endif
 
 template <int M>
 void launch_finalize_m(const FinalizeArgs& f, long n, hipStream_t st) {
