@@ -8,6 +8,7 @@
 // CPU specific; see DESIGN.md "Numerics").  This file is compiled with
 // -ffp-contract=off: the only fused operations are the explicit fma() calls.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
@@ -175,10 +176,27 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
                 }
             }
         }
-        if (a.xt) {
+    }
+    if (a.xt) {
+        // Transformed rows go out through a wave-private LDS tile (64 rows x 8 KS columns, two
+        // passes) so that every store instruction writes whole 64..128-byte row segments instead of
+        // 64 scattered 8-byte words.  DS operations of one wave execute in order: no barrier.
+        constexpr int HC = 8 * KS;
+        __shared__ double tile_all[4][64 * (HC + 1)];
+        double* tile = tile_all[threadIdx.x >> 6];
+        const int lane = threadIdx.x & 63;
+        const long q0 = q - lane;
 #pragma unroll
-            for (int k = 0; k < DP; ++k)
-                if (k < a.d) a.xt[q * a.d + k] = acc[k];
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int k = 0; k < HC; ++k) tile[lane * (HC + 1) + k] = acc[h * HC + k];
+#pragma unroll
+            for (int it = 0; it < HC; ++it) {
+                const int e = it * 64 + lane;
+                const int row = e / HC, col = e % HC;
+                const int kc = h * HC + col;
+                if (kc < a.d && q0 + row < a.nq) a.xt[(q0 + row) * a.d + kc] = tile[row * (HC + 1) + col];
+            }
         }
     }
     if (!a.qimg) return;
@@ -294,26 +312,67 @@ struct FinalizeArgs {
     int* fail_count;
 };
 
-template <int LPQ>
-__device__ __forceinline__ double group_min(double v) {
-#pragma unroll
-    for (int o = LPQ / 2; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, LPQ));
-    return v;
-}
-template <int LPQ>
-__device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int o = LPQ / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, LPQ));
-    return v;
-}
-template <int LPQ>
-__device__ __forceinline__ int group_min_i(int v) {
-#pragma unroll
-    for (int o = LPQ / 2; o > 0; o >>= 1) {
-        const int w = __shfl_xor(v, o, LPQ);
-        v = w < v ? w : v;
+// Lane exchange inside the group of LPQ lanes that share a query.  LPQ = 16 is one DPP row: the
+// value of every other lane of the row is visited with the 15 row rotations (`row_ror:n`, a VALU
+// move with no LDS traffic and no wait); wider groups use ds_bpermute shuffles.  Only the multiset
+// of peers matters to the callers, which rotate the peer's lane number along when they need it.
+template <int LPQ, int N>
+__device__ __forceinline__ int peer_i(int v, int c) {
+    if constexpr (LPQ == 16) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false);
+    } else {
+        return __shfl(v, (c + N) % LPQ, LPQ);
     }
-    return v;
+}
+template <int LPQ, int N>
+__device__ __forceinline__ float peer_f(float v, int c) {
+    return __int_as_float(peer_i<LPQ, N>(__float_as_int(v), c));
+}
+template <int LPQ, int N>
+__device__ __forceinline__ long peer_l(long v, int c) {
+    const int lo = peer_i<LPQ, N>((int)(unsigned)(unsigned long)v, c);
+    const int hi = peer_i<LPQ, N>((int)((unsigned long)v >> 32), c);
+    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+template <int LPQ, int N>
+__device__ __forceinline__ double peer_d(double v, int c) {
+    return __longlong_as_double(peer_l<LPQ, N>(__double_as_longlong(v), c));
+}
+// f(integral_constant<int, n>) for n = 1 .. LPQ-1
+template <int LPQ, int N = 1, typename F>
+__device__ __forceinline__ void for_each_peer(F&& f) {
+    if constexpr (N < LPQ) {
+        f(std::integral_constant<int, N>{});
+        for_each_peer<LPQ, N + 1>(f);
+    }
+}
+
+template <int LPQ, int O = LPQ / 2>
+__device__ __forceinline__ double group_min(double v, int c) {
+    if constexpr (O > 0) {
+        v = fmin(v, peer_d<LPQ, O>(v, c));
+        return group_min<LPQ, O / 2>(v, c);
+    } else {
+        return v;
+    }
+}
+template <int LPQ, int O = LPQ / 2>
+__device__ __forceinline__ double group_max(double v, int c) {
+    if constexpr (O > 0) {
+        v = fmax(v, peer_d<LPQ, O>(v, c));
+        return group_max<LPQ, O / 2>(v, c);
+    } else {
+        return v;
+    }
+}
+template <int LPQ, int O = LPQ / 2>
+__device__ __forceinline__ int group_min_i(int v, int c) {
+    if constexpr (O > 0) {
+        const int w = peer_i<LPQ, O>(v, c);
+        return group_min_i<LPQ, O / 2>(w < v ? w : v, c);
+    } else {
+        return v;
+    }
 }
 
 template <int M>
@@ -324,7 +383,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     long q = gt / LPQ;
     const int c = (int)(gt % LPQ);
     const bool live = q < s.nq;
-    if (!live) q = s.nq - 1;  // keep the lane for the shuffles; it writes nothing
+    if (!live) q = s.nq - 1;  // keep the lane for the exchanges; it writes nothing
 
     const int list = c / M, slot = c % M;
     const bool has_slot = slot < a.m_list;
@@ -341,12 +400,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const double eps = a.eps_c * nrm * nrm;
     const float cve = valid ? cv : INFINITY;
     int rank_c = 0;
-#pragma unroll
-    for (int j = 0; j < LPQ; ++j) {
-        const float cj = __shfl(cve, j, LPQ);
-        rank_c += (cj < cve) || (cj == cve && j < c);
-    }
-    const double tau_c = group_min<LPQ>(rank_c >= s.kk - 1 ? (double)cve : INFINITY);
+    for_each_peer<LPQ>([&](auto n) {
+        const float cj = peer_f<LPQ, n.value>(cve, c);
+        const int pj = peer_i<LPQ, n.value>(c, c);
+        rank_c += (cj < cve) || (cj == cve && pj < c);
+    });
+    const double tau_c = group_min<LPQ>(rank_c >= s.kk - 1 ? (double)cve : INFINITY, c);
     const bool need = valid && ((double)cv <= tau_c + 2.0 * eps);
 
     double d2 = INFINITY;
@@ -356,17 +415,16 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const int key_id = usable ? id : (0x7fffff00 + c);  // unusable slots sort last, distinct
 
     // rank by (d2, index)
-    int rank = 0, n_usable = 0;
-#pragma unroll
-    for (int j = 0; j < LPQ; ++j) {
-        const double dj = __shfl(d2, j, LPQ);
-        const int ij = __shfl(key_id, j, LPQ);
+    int rank = 0, n_usable = usable ? 1 : 0;
+    for_each_peer<LPQ>([&](auto n) {
+        const double dj = peer_d<LPQ, n.value>(d2, c);
+        const int ij = peer_i<LPQ, n.value>(key_id, c);
         rank += (dj < d2) || (dj == d2 && ij < key_id);
         n_usable += dj < INFINITY;
-    }
+    });
 
     // certificate: every reference outside the lists has a float64 d2 above tau
-    const double tau = group_min<LPQ>(rank >= s.kk - 1 ? d2 : INFINITY);
+    const double tau = group_min<LPQ>(rank >= s.kk - 1 ? d2 : INFINITY, c);
     // Bound on everything outside the lists: the m_list-th smallest entry of the two lists together
     // (sentinels included), max_i min(a_i, b_{m-1-i}) -- the value the pre-filter's rejections were
     // tested against last (coarse.hip.h, pair_union_rank_m).
@@ -374,7 +432,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const int partner = M + (has_slot ? a.m_list - 1 - slot : 0);
     const float cv_partner = __shfl(cv_raw, partner, LPQ);
     const double t_pair = (list == 0 && has_slot) ? (double)fminf(cv_raw, cv_partner) : -INFINITY;
-    const double t_min = group_max<LPQ>(t_pair);
+    const double t_min = group_max<LPQ>(t_pair, c);
     const double bound = (qn + t_min - eps) * a.inv_s2;
     bool certified = (n_usable >= s.kk) && (tau < INFINITY) && (bound > tau);
     // Exactly tied float64 distances: which tied row the reference keeps at the k-th slot (and,
@@ -383,14 +441,13 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     {
         const bool mine = usable && (rank < s.kk);
         int ties = 0;
-#pragma unroll
-        for (int j = 0; j < LPQ; ++j) {
-            const double dj = __shfl(d2, j, LPQ);
-            const int rj = __shfl(rank, j, LPQ);
-            if (s.deterministic) ties += (dj == d2) && mine && (rj >= s.kk);          // tie across the boundary
-            else ties += (dj == d2) && mine && (rj != rank);                            // any tie involving a kept row
-        }
-        const int any_tie = group_min_i<LPQ>(-ties);
+        for_each_peer<LPQ>([&](auto n) {
+            const double dj = peer_d<LPQ, n.value>(d2, c);
+            const int rj = peer_i<LPQ, n.value>(rank, c);
+            if (s.deterministic) ties += (dj == d2) && mine && (rj >= s.kk);  // tie across the boundary
+            else ties += (dj == d2) && mine;                                    // any tie involving a kept row
+        });
+        const int any_tie = group_min_i<LPQ>(-ties, c);
         if (any_tie < 0) certified = false;
     }
 
@@ -400,7 +457,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const long self_id = s.row_offset + q;
     if (s.exclude_self) {
         const bool is_self = usable && (long)id == self_id && rank < s.kk;
-        int drop = group_min_i<LPQ>(is_self ? rank : 0x7fffffff);
+        int drop = group_min_i<LPQ>(is_self ? rank : 0x7fffffff, c);
         if (drop == 0x7fffffff) drop = 0;
         sel = rank == drop ? -1 : (rank > drop ? rank - 1 : rank);
     }
@@ -410,21 +467,21 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     int pos = sel;
     if (s.deterministic) {
         // REF/src/sknnr/_base.py:166-175
-        const double dmax = group_max<LPQ>(chosen ? dist : 0.0);
+        const double dmax = group_max<LPQ>(chosen ? dist : 0.0, c);
         const double row_scale = fmax(dmax, 1.0);
         const double k0 = chosen ? round_key(dist / row_scale, s.pow10, s.pow10_is_divisor) : INFINITY;
         long k1 = (long)id - self_id;
         k1 = k1 < 0 ? -k1 : k1;
+        const int tagged = key_id | (chosen ? (int)0x80000000u : 0);  // key_id >= 0: bit 31 carries `chosen`
         pos = 0;
-#pragma unroll
-        for (int j = 0; j < LPQ; ++j) {
-            const double k0j = __shfl(k0, j, LPQ);
-            const long k1j = __shfl(k1, j, LPQ);
-            const int ij = __shfl(key_id, j, LPQ);
-            const bool chj = __shfl((int)chosen, j, LPQ) != 0;
+        for_each_peer<LPQ>([&](auto n) {
+            const double k0j = peer_d<LPQ, n.value>(k0, c);
+            const long k1j = peer_l<LPQ, n.value>(k1, c);
+            const int tj = peer_i<LPQ, n.value>(tagged, c);
+            const int ij = tj & 0x7fffffff;
             const bool less = (k0j < k0) || (k0j == k0 && (k1j < k1 || (k1j == k1 && ij < key_id)));
-            pos += chj && less;
-        }
+            pos += (tj < 0) && less;
+        });
     }
     if (live && chosen) {
         if (s.out_dist) s.out_dist[q * s.k + pos] = dist;
