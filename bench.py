@@ -149,31 +149,29 @@ def main():
     def step():
         if not (use_dist and not args.no_gather):
             return eng.kneighbors(q, k, apply_affine=True, deterministic=True, row_offset=rank * nq)
-        # N > 1: every rank answers its own block (global row offset rank * nq) chunk by chunk; the
-        # RCCL all-gather of a finished chunk runs on a side stream under the next chunk's kernels.
-        d_all = torch.empty((world, nq, k), dtype=torch.float64, device="cuda")
-        i_all = torch.empty((world, nq, k), dtype=torch.int64, device="cuda")
+        # N > 1: the job's rows are dealt to the ranks chunk-cyclically -- chunk c of every rank forms
+        # the contiguous global rows [W*a, W*b) with this rank's block at slot `rank` -- so each rank
+        # writes its chunk straight into its slot of the final arrays and the RCCL all-gather of a
+        # finished chunk is in place (no staging copies), on a side stream, under the next chunk's
+        # kernels.  (Every block is contiguous, so its global row offset is all the reorder needs.)
+        d_all = torch.empty((world * nq, k), dtype=torch.float64, device="cuda")
+        i_all = torch.empty((world * nq, k), dtype=torch.int64, device="cuda")
         works = []
         for a in range(0, nq, gather_chunk):
             b = min(nq, a + gather_chunk)
-            d, i = eng.kneighbors(q[a:b], k, apply_affine=True, deterministic=True, row_offset=rank * nq + a)
+            lo = world * a + rank * (b - a)
+            d_own, i_own = d_all[lo: lo + (b - a)], i_all[lo: lo + (b - a)]
+            eng.kneighbors(q[a:b], k, apply_affine=True, deterministic=True, row_offset=lo, out=(d_own, i_own))
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(done)
-                d_recv = torch.empty((world, b - a, k), dtype=torch.float64, device="cuda")
-                i_recv = torch.empty((world, b - a, k), dtype=torch.int64, device="cuda")
-                w1 = dist.all_gather_into_tensor(d_recv, d, async_op=True)
-                w2 = dist.all_gather_into_tensor(i_recv, i, async_op=True)
-                works.append((a, b, d, i, d_recv, i_recv, w1, w2))
-        for a, b, _d, _i, d_recv, i_recv, w1, w2 in works:
-            w1.wait()
-            w2.wait()
-            with torch.cuda.stream(comm_stream):
-                d_all[:, a:b] = d_recv
-                i_all[:, a:b] = i_recv
+                works.append(dist.all_gather_into_tensor(d_all[world * a: world * b], d_own, async_op=True))
+                works.append(dist.all_gather_into_tensor(i_all[world * a: world * b], i_own, async_op=True))
+        for w in works:
+            w.wait()
         torch.cuda.current_stream().wait_stream(comm_stream)
-        return d_all.view(world * nq, k), i_all.view(world * nq, k)
+        return d_all, i_all
 
     def barrier():
         torch.cuda.synchronize()

@@ -96,9 +96,11 @@ class KNNEngine:
 
     def kneighbors(self, X, k, *, exclude_self=False, deterministic=True, decimals=10,
                    formula="expanded", apply_affine=False, row_offset=0, n_self_rows=None,
-                   return_distance=True):
+                   return_distance=True, out=None):
         """Neighbours of the rows of ``X`` (numpy -> numpy, torch.cuda -> torch.cuda), or of
-        the reference rows ``[row_offset, row_offset + n_self_rows)`` when ``X`` is None."""
+        the reference rows ``[row_offset, row_offset + n_self_rows)`` when ``X`` is None.
+        ``out=(dist, idx)``: contiguous float64 / int64 CUDA tensors of shape ``(nq, k)`` to write
+        into (torch.cuda input only), e.g. this rank's slot of an all-gather buffer."""
         opts = self._opts(k, exclude_self=exclude_self, deterministic=deterministic,
                           decimals=decimals, formula=formula,
                           apply_affine=apply_affine and X is not None, row_offset=row_offset)
@@ -116,14 +118,27 @@ class KNNEngine:
                 raise ValueError(f"X is on cuda:{X.device.index}, the engine on cuda:{self.device}")
             self._check_columns(X, apply_affine)
             nq = X.shape[0]
-            idx = torch.empty((nq, k), dtype=torch.int64, device=X.device)
-            dist = torch.empty((nq, k), dtype=torch.float64, device=X.device) if return_distance else None
+            if out is not None:
+                dist, idx = out
+                for t_, dt_ in ((dist, torch.float64), (idx, torch.int64)):
+                    if t_ is None:
+                        continue
+                    if (tuple(t_.shape) != (nq, k) or t_.dtype != dt_ or not t_.is_contiguous()
+                            or t_.device != X.device):
+                        raise ValueError(f"out tensors must be contiguous ({nq}, {k}) {dt_} on {X.device}")
+                if idx is None:
+                    raise ValueError("out needs an index tensor")
+            else:
+                idx = torch.empty((nq, k), dtype=torch.int64, device=X.device)
+                dist = torch.empty((nq, k), dtype=torch.float64, device=X.device) if return_distance else None
             if nq:
                 stream = torch.cuda.current_stream(X.device).cuda_stream
                 self._index.kneighbors_device(X.data_ptr(), nq, opts,
                                               dist.data_ptr() if dist is not None else 0,
                                               idx.data_ptr(), stream)
             return dist, idx
+        if out is not None:
+            raise ValueError("out= is only supported for torch.cuda inputs")
         X = np.ascontiguousarray(X, dtype=np.float64)
         self._check_columns(X, apply_affine)
         return self._index.kneighbors_host(X, opts, return_distance=return_distance)

@@ -410,6 +410,31 @@ def test_host_buffer_pipeline_matches_device_path(N, O):
     eng.close()
 
 
+def test_engine_writes_into_caller_tensors(N, O):
+    """out=(dist, idx): results land in the caller's (slot of a larger) tensors; wrong shapes raise."""
+    import torch
+
+    from sknnr_amd._engine import KNNEngine
+
+    x_ref, _, x_q = _synth(1500, 700, 10)
+    eng = KNNEngine(x_ref)
+    xq = torch.as_tensor(x_q, device="cuda")
+    k = 4
+    big_d = torch.full((3 * 700, k), -1.0, dtype=torch.float64, device="cuda")
+    big_i = torch.full((3 * 700, k), -1, dtype=torch.int64, device="cuda")
+    d, i = eng.kneighbors(xq, k, row_offset=700, out=(big_d[700:1400], big_i[700:1400]))
+    od, oi = O.kneighbors(x_ref, x_q, k, "expanded", row_offset=700)
+    np.testing.assert_array_equal(big_i[700:1400].cpu().numpy(), oi)
+    np.testing.assert_array_equal(big_d[700:1400].cpu().numpy(), od)
+    assert d.data_ptr() == big_d[700:1400].data_ptr() and i.data_ptr() == big_i[700:1400].data_ptr()
+    assert (big_i[:700] == -1).all() and (big_i[1400:] == -1).all()   # neighbours' slots untouched
+    with pytest.raises(ValueError):
+        eng.kneighbors(xq, k, out=(big_d[:699], big_i[:699]))
+    with pytest.raises(ValueError):
+        eng.kneighbors(x_q, k, out=(big_d[:700], big_i[:700]))          # numpy input
+    eng.close()
+
+
 def test_two_indexes_alive_and_reused(N, O):
     """Handles are independent and reusable across calls of different shapes."""
     a_ref, a_y, a_q = _synth(900, 300, 12)
