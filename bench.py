@@ -124,7 +124,7 @@ def main():
     from sknnr_amd import synth
     from sknnr_amd._engine import KNNEngine
     from sknnr_amd._native import affine_transform_host
-    from sknnr_amd.distributed import ShardedKNN, all_gather_rows
+    from sknnr_amd.distributed import cyclic_slot
     from sknnr_amd.transformers import CCATransformer
 
     # ---- fit (host, once): CCA ordination of the synthetic reference set -> affine map ------
@@ -159,7 +159,7 @@ def main():
         works = []
         for a in range(0, nq, gather_chunk):
             b = min(nq, a + gather_chunk)
-            lo = world * a + rank * (b - a)
+            lo = cyclic_slot(world, rank, a, b)
             d_own, i_own = d_all[lo: lo + (b - a)], i_all[lo: lo + (b - a)]
             eng.kneighbors(q[a:b], k, apply_affine=True, deterministic=True, row_offset=lo, out=(d_own, i_own))
             done = torch.cuda.Event()

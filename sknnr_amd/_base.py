@@ -178,13 +178,13 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
         return int(n_neighbors)
 
     def _kneighbors_engine(self, X, k, *, apply_affine, use_deterministic_ordering, row_offset=0,
-                           n_self_rows=None, return_distance=True):
+                           n_self_rows=None, return_distance=True, out=None):
         try:
             return self.engine_.kneighbors(
                 X, k, exclude_self=X is None, deterministic=use_deterministic_ordering,
                 decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
                 apply_affine=apply_affine, row_offset=row_offset, n_self_rows=n_self_rows,
-                return_distance=return_distance)
+                return_distance=return_distance, out=out)
         except _native.HipBackendError as err:
             if err.code == _native.ERR_K_TOO_LARGE:
                 raise ValueError(err.message) from None

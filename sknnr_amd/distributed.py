@@ -20,7 +20,7 @@ from typing import Callable
 
 import numpy as np
 
-__all__ = ["shard_bounds", "all_gather_rows", "ShardedKNN"]
+__all__ = ["shard_bounds", "cyclic_slot", "all_gather_rows", "ShardedKNN"]
 
 
 def shard_bounds(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -28,6 +28,14 @@ def shard_bounds(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
     base, rem = divmod(int(n_rows), int(world_size))
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def cyclic_slot(world_size: int, rank: int, a: int, b: int) -> int:
+    """Chunk-cyclic dealing of a job's rows: every rank holds ``n_local`` rows, cut at the same
+    positions ``[a, b)`` into chunks; chunk ``[a, b)`` of all ranks together forms the contiguous
+    global rows ``[W*a, W*b)`` with rank ``r``'s block at ``W*a + r*(b-a)`` (returned).  A finished
+    chunk can then be all-gathered *in place* into the final arrays."""
+    return int(world_size) * int(a) + int(rank) * (int(b) - int(a))
 
 
 def _max_rows(n_rows: int, world_size: int) -> int:
@@ -94,6 +102,7 @@ class ShardedKNN:
         self.world_size = dist.get_world_size(group)
         self._local_kneighbors = local_kneighbors or self._engine_kneighbors
         self._local_predict = local_predict or self._engine_predict
+        self._local_out = local_kneighbors is None  # the engine can write into caller tensors
 
     # ---- local engines ------------------------------------------------------------------
     def _reg(self):
@@ -101,12 +110,12 @@ class ShardedKNN:
         return getattr(est, "regressor_", est), hasattr(est, "regressor_")
 
     def _engine_kneighbors(self, X_block, row_offset, n_neighbors, use_deterministic_ordering=True,
-                           n_self_rows=None):
+                           n_self_rows=None, out=None):
         reg, transformed = self._reg()
         k = reg._resolve_k(n_neighbors)
         return reg._kneighbors_engine(X_block, k, apply_affine=transformed and X_block is not None,
                                       use_deterministic_ordering=use_deterministic_ordering,
-                                      row_offset=row_offset, n_self_rows=n_self_rows)
+                                      row_offset=row_offset, n_self_rows=n_self_rows, out=out)
 
     def _engine_predict(self, X_block, row_offset, n_self_rows=None):
         reg, transformed = self._reg()
@@ -241,3 +250,51 @@ class ShardedKNN:
                     out_i[ra + lo : ra + hi] = i_all[r * rows : r * rows + (hi - lo)]
         compute.wait_stream(comm)
         return out_d, out_i
+
+    def kneighbors_cyclic(self, X_block, n_neighbors=None, *, chunk_rows=2_500_000,
+                          use_deterministic_ordering=True):
+        """Rows dealt chunk-cyclically (:func:`cyclic_slot`; every rank passes the same number of
+        rows): each rank writes a finished chunk straight into its slot of the final
+        ``(W*n_local, k)`` arrays and the all-gather of that chunk is in place -- no staging
+        copies -- and, under nccl/RCCL, issued on a side stream so that it travels under the next
+        chunk's kernels.  Returns the complete ``(dist, idx)`` in global row order on every rank."""
+        import torch
+        import torch.distributed as dist
+
+        reg = self._reg()[0] if self.estimator is not None else None
+        k = reg._resolve_k(n_neighbors) if reg is not None else int(n_neighbors)
+        W, r = self.world_size, self.rank
+        n_local = X_block.shape[0]
+        on_gpu = isinstance(X_block, torch.Tensor) and X_block.is_cuda
+        dev = X_block.device if on_gpu else torch.device("cpu")
+        d_all = torch.empty((W * n_local, k), dtype=torch.float64, device=dev)
+        i_all = torch.empty((W * n_local, k), dtype=torch.int64, device=dev)
+        comm = torch.cuda.Stream(device=dev) if on_gpu else None
+        works = []
+        for a in range(0, n_local, chunk_rows):
+            b = min(n_local, a + chunk_rows)
+            lo = cyclic_slot(W, r, a, b)
+            d_own, i_own = d_all[lo: lo + (b - a)], i_all[lo: lo + (b - a)]
+            d_l, i_l = self._local_kneighbors(X_block[a:b], lo, k,
+                                              use_deterministic_ordering=use_deterministic_ordering,
+                                              **({"out": (d_own, i_own)} if self._local_out else {}))
+            if not self._local_out:
+                d_own.copy_(torch.as_tensor(d_l))
+                i_own.copy_(torch.as_tensor(i_l))
+            if W == 1:
+                continue
+            if on_gpu:
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(comm):
+                    comm.wait_event(done)
+                    works.append(dist.all_gather_into_tensor(d_all[W * a: W * b], d_own, group=self.group, async_op=True))
+                    works.append(dist.all_gather_into_tensor(i_all[W * a: W * b], i_own, group=self.group, async_op=True))
+            else:
+                works.append(dist.all_gather_into_tensor(d_all[W * a: W * b], d_own, group=self.group, async_op=True))
+                works.append(dist.all_gather_into_tensor(i_all[W * a: W * b], i_own, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if on_gpu:
+            torch.cuda.current_stream(dev).wait_stream(comm)
+        return d_all, i_all

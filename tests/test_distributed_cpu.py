@@ -54,8 +54,23 @@ def _worker(rank, world, port, n_q, out_dir):
         d_self, i_self = sh.kneighbors(None, 4, n_rows_total=300)
         p_all = sh.predict(x_q)
         p_self = sh.predict(None, n_rows_total=300)
+        # chunk-cyclic dealing with in-place all-gathers (bench.py's N > 1 layout): 30 rows per rank
+        # in chunks of 8 (ragged last chunk); rank r's chunk [a, b) holds global rows W*a + r*(b-a) ...
+        import torch
+
+        from sknnr_amd.distributed import cyclic_slot
+
+        n_loc, chunk = 30, 8
+        glob = np.concatenate([x_q, x_q[::-1]])[: world * n_loc] if 2 * n_q >= world * n_loc else None
+        d_cyc = i_cyc = np.zeros((0, 4))
+        if glob is not None:
+            mine = np.concatenate([glob[cyclic_slot(world, rank, a, min(n_loc, a + chunk)):
+                                        cyclic_slot(world, rank, a, min(n_loc, a + chunk)) + min(n_loc, a + chunk) - a]
+                                   for a in range(0, n_loc, chunk)])
+            d_c, i_c = sh.kneighbors_cyclic(torch.as_tensor(mine), 4, chunk_rows=chunk)
+            d_cyc, i_cyc = d_c.numpy(), i_c.numpy()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), d_all=d_all, i_all=i_all, d_blk=d_blk, i_blk=i_blk,
-                 d_self=d_self, i_self=i_self, p_all=p_all, p_self=p_self)
+                 d_self=d_self, i_self=i_self, p_all=p_all, p_self=p_self, d_cyc=d_cyc, i_cyc=i_cyc)
     finally:
         dist.destroy_process_group()
 
@@ -84,6 +99,11 @@ def test_two_rank_sharding_matches_single_call(tmp_path, n_q):
         np.testing.assert_array_equal(r["d_self"], ds)
         np.testing.assert_array_equal(r["p_all"], O.predict(y, d, i, "distance"))
         np.testing.assert_array_equal(r["p_self"], O.predict(y, ds, is_, "distance"))
+        if 2 * n_q >= world * 30:
+            glob = np.concatenate([x_q, x_q[::-1]])[: world * 30]
+            dg, ig = O.kneighbors(x_ref, glob, 4, "expanded")
+            np.testing.assert_array_equal(r["i_cyc"], ig)
+            np.testing.assert_array_equal(r["d_cyc"], dg)
 
 
 def test_shard_bounds_partition_the_rows():
