@@ -116,6 +116,13 @@ __device__ unsigned long long coarse_counters[16];
 #endif
 
 
+// Wave priorities: a wave that handles a visit (corrections, hit scan) runs ahead of sweeping waves;
+// measured 1.3 % faster than priority 1 for the MFMAs only.
+#ifndef SKNNR_PRIO_CORR
+#define SKNNR_PRIO_CORR 2
+#define SKNNR_PRIO_SCAN 2
+#endif
+
 constexpr int kQueueCap = 4;
 constexpr int kQueueFlushAt = 3;
 __host__ __device__ constexpr int queue_bytes_per_wave(int nqb) { return nqb * kQueueCap * 64 * 8; }
@@ -379,9 +386,9 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 CTR(1, 1);
                 CTR(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(m1 < loose)));
                 CTR(12, __builtin_amdgcn_ballot_w64(m1 < thr[qb]) != 0);
-                __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(SKNNR_PRIO_CORR);
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(SKNNR_PRIO_SCAN);
                 const unsigned qlane = qwave + qb * (kQueueCap * 512);
                 // (take_hit's compare is compiler-visible: it is the hazard-padded first reader of the
                 // corrected accumulator)
@@ -394,6 +401,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                             take_hit<M>(acc[r], id_base + acc_row(r, 0), vals[qb], idxs[qb], thr[qb], cnt[qb], qlane CTR_PASS);
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
                 TSTAMP(3);  // corrections + hit scan
                 if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) {
                     CTR(6, 1);
