@@ -39,17 +39,26 @@ __host__ __device__ constexpr int tile_frag_bytes(int ks) { return 2 * ks * 1024
 __host__ __device__ constexpr int tile_bytes(int ks) { return 2 * ks * 1024 + 128; }
 // 32-reference tiles per LDS stage.  One 16-wave workgroup per CU (4 waves per SIMD) shares the
 // stage: two stage buffers + the waves' candidate queues must fit the 160 KiB of LDS.
-__host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 8 : (ks <= 4 ? 2 : 1); }
+__host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 8 : (ks <= 4 ? 4 : 2); }
 // Row of the 32x32 accumulator held in register r of a lane in half h (guide section 3).
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // Launch geometry by feature width (KS) and list length (M):
-//   narrow features and short lists: 16 waves (one 1024-thread workgroup per CU, 4 waves per SIMD at
-//   <= 128 VGPR); otherwise 8 waves (2 per SIMD, <= 256 VGPR).  Two 32-query blocks per wave while the
-//   registers allow it.
+//   light  (KS <= 2, M <= 16): 16 waves -- one 1024-thread workgroup per CU, 4 waves per SIMD at <= 128 VGPR;
+//   medium (KS 3..6, M <= 8; KS 7, M 6) : 12 waves -- 3 per SIMD at <= 170 VGPR (lo fragments fetched on demand);
+//   heavy  (the rest)        :  8 waves -- 2 per SIMD, <= 256 VGPR.
+//   Two 32-query blocks per wave while the registers allow it.
 __host__ __device__ constexpr bool coarse_is_light(int ks, int m) { return ks <= 2 && m <= 16; }
-__host__ __device__ constexpr int coarse_waves(int ks, int m) { return coarse_is_light(ks, m) ? 16 : 8; }
-__host__ __device__ constexpr int coarse_wps(int ks, int m) { return coarse_is_light(ks, m) ? 4 : 2; }
+__host__ __device__ constexpr bool coarse_is_medium(int ks, int m) {
+    return (ks >= 3 && ks <= 6 && m <= 8) || (ks == 7 && m <= 6);
+}
+__host__ __device__ constexpr int coarse_waves(int ks, int m) {
+    return coarse_is_light(ks, m) ? 16 : (coarse_is_medium(ks, m) ? 12 : 8);
+}
+__host__ __device__ constexpr int coarse_wps(int ks, int m) {
+    return coarse_is_light(ks, m) ? 4 : (coarse_is_medium(ks, m) ? 3 : 2);
+}
+__host__ __device__ constexpr bool coarse_lo_on_demand(int ks, int m) { return coarse_is_medium(ks, m); }
 __host__ __device__ constexpr int coarse_nqb(int ks, int m) { return (ks <= 4 && m <= 8) ? 2 : 1; }
 
 // v_min3_f32 / v_min_f32 as raw instructions: the compiler would put a canonicalising
@@ -268,6 +277,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
     const int half = lane >> 5;
     constexpr int WAVES = coarse_waves(KS, M);
     constexpr int NQB = coarse_nqb(KS, M);
+    constexpr bool LO_ON_DEMAND = coarse_lo_on_demand(KS, M);
     const int qb0 = (blockIdx.x * WAVES + wave) * NQB;
     const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue_bytes_per_wave(NQB) + lane * 8);
 
@@ -336,12 +346,16 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 #pragma unroll 1
         for (int t = 0; t < TPS; ++t) {
             const char* tb = cur + t * TB;
+            // The lo fragments of the tile are only needed by the correction products: with
+            // LO_ON_DEMAND (wide features, where they are 4 KS registers) they are fetched by the
+            // first q-block of the tile that is visited.
             half8 ah[KS], al[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 ah[s] = *(const half8*)(tb + (0 * KS + s) * 1024 + lane * 16);
-                al[s] = *(const half8*)(tb + (1 * KS + s) * 1024 + lane * 16);
+                if (!LO_ON_DEMAND) al[s] = *(const half8*)(tb + (1 * KS + s) * 1024 + lane * 16);
             }
+            bool have_lo = !LO_ON_DEMAND;
             floatx16 c0;
             {
                 const floatx4* cp = (const floatx4*)(tb + tile_frag_bytes(KS) + half * 64);
@@ -386,6 +400,11 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 CTR(1, 1);
                 CTR(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(m1 < loose)));
                 CTR(12, __builtin_amdgcn_ballot_w64(m1 < thr[qb]) != 0);
+                if (LO_ON_DEMAND && !have_lo) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) al[s] = *(const half8*)(tb + (1 * KS + s) * 1024 + lane * 16);
+                    have_lo = true;
+                }
                 __builtin_amdgcn_s_setprio(SKNNR_PRIO_CORR);
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
                 __builtin_amdgcn_s_setprio(SKNNR_PRIO_SCAN);

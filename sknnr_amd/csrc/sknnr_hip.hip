@@ -116,8 +116,8 @@ struct DevBuf {
 };
 
 constexpr int kMaxKs = 8;              // coarse path: d <= 128
-constexpr long kRowQuantum = 1024;  // query-row padding: multiple of every coarse geometry (1024, 512, 256 rows per workgroup)
-constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk (multiple of kRowQuantum)
+constexpr long kRowQuantum = 3072;  // query-row padding: multiple of every coarse geometry (1024, 768, 512, 256 rows per workgroup)
+constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk (each chunk is padded to kRowQuantum)
 constexpr int kScanMaxKK = 192;
 // Error budget of the split contraction, in units of 2^-24 (|q'| + max|r'|)^2:
 // eps_units(ks) = 8 + 4 ks.  Measured worst case on gfx950 over 5e5 pairs per shape
