@@ -229,43 +229,56 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
 // formula 0: |x|^2 + (-2 x.y) + |y|^2, clamped at 0   (_argkmin.pyx.tp:492-502)
 // formula 1: sum (x - y)^2, mul and add separately rounded (_dist_metrics.pxd.tp:39-49)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double pair_d2(const double* __restrict__ x, const double* __restrict__ r,
-                                          int d, double rn, int formula) {
+template <int FORMULA>
+__device__ __forceinline__ double pair_d2_f(const double* __restrict__ x, const double* __restrict__ r,
+                                            int d, double rn) {
     double qn = 0.0, acc = 0.0;
     int c = 0;
-    if ((d & 1) == 0) {  // rows start 16-byte aligned: two elements per load, same k order
+    auto step = [&](double xv, double rv) {  // one feature, in ascending k order
+        if (FORMULA == 0) {
+            qn = fma(xv, xv, qn);
+            acc = fma(xv, rv, acc);
+        } else {
+            const double t = xv - rv;
+            acc = acc + t * t;  // -ffp-contract=off keeps the two roundings
+        }
+    };
+    if ((d & 1) == 0) {  // rows start 16-byte aligned: two elements per load
         const double2* x2 = (const double2*)x;
         const double2* r2 = (const double2*)r;
-        for (; c < d; c += 2) {
-            const double2 xv = x2[c >> 1], rv = r2[c >> 1];
-            if (formula == 0) {
-                qn = fma(xv.x, xv.x, qn);
-                acc = fma(xv.x, rv.x, acc);
-                qn = fma(xv.y, xv.y, qn);
-                acc = fma(xv.y, rv.y, acc);
-            } else {
-                const double t0 = xv.x - rv.x;
-                acc = acc + t0 * t0;  // -ffp-contract=off keeps the two roundings
-                const double t1 = xv.y - rv.y;
-                acc = acc + t1 * t1;
+        // eight features per trip, all eight 16-byte loads issued before the first use (sixteen per
+        // trip measured slower): the row
+        // gathers come from L2 / Infinity Cache and a lane that waits for each load in turn is
+        // bound by their latency
+        for (; c + 8 <= d; c += 8) {
+            double2 xv[4], rv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rv[i] = r2[(c >> 1) + i];
+                xv[i] = x2[(c >> 1) + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                step(xv[i].x, rv[i].x);
+                step(xv[i].y, rv[i].y);
             }
         }
-    }
-    for (; c < d; ++c) {
-        const double xv = x[c];
-        if (formula == 0) {
-            qn = fma(xv, xv, qn);
-            acc = fma(xv, r[c], acc);
-        } else {
-            const double t = xv - r[c];
-            acc = acc + t * t;
+        for (; c < d; c += 2) {
+            const double2 xv = x2[c >> 1], rv = r2[c >> 1];
+            step(xv.x, rv.x);
+            step(xv.y, rv.y);
         }
     }
-    if (formula == 0) {
+    for (; c < d; ++c) step(x[c], r[c]);
+    if (FORMULA == 0) {
         const double d2 = qn + (-2.0 * acc) + rn;
         return d2 > 0.0 ? d2 : 0.0;
     }
     return acc;
+}
+__device__ __forceinline__ double pair_d2(const double* __restrict__ x, const double* __restrict__ r,
+                                          int d, double rn, int formula) {
+    return formula == 0 ? pair_d2_f<0>(x, r, d, rn) : pair_d2_f<1>(x, r, d, rn);
 }
 
 struct SelectArgs {
