@@ -47,7 +47,7 @@ def run(name, nq, n_ref, d, k, t=0, weight_mode=0, reps=3):
 if __name__ == "__main__":
     run("configs[1] Euclidean", 1_000_000, 10_000, 16, 5)
     run("bench line", 10_000_000, 50_000, 32, 5)
-    run("configs[2] GNN k=7 distance-weighted predict", 10_000_000, 50_000, 32, 7, t=8, weight_mode=1)
+    run("configs[2] GNN k=7 distance-weighted predict T=40", 10_000_000, 50_000, 32, 7, t=40, weight_mode=1)
     run("configs[3] Mahalanobis d=64 (one GPU's share of 10M/8)", 1_250_000, 50_000, 64, 5)
     run("configs[3] Mahalanobis d=64, 10M on one GPU", 10_000_000, 50_000, 64, 5, reps=2)
     run("configs[4] MSN d=8 k=1 100k refs (one GPU's share of 50M/8)", 6_250_000, 100_000, 8, 1)

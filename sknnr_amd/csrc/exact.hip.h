@@ -870,12 +870,58 @@ __device__ __forceinline__ double np_sum(int n, F term) {
     return res;
 }
 
+// np_sum for n <= 8 terms held in registers (static indexing only).
+__device__ __forceinline__ double np_sum_small(int n, const double (&v)[8]) {
+    if (n == 8) return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    double r = v[0];
+#pragma unroll
+    for (int i = 1; i < 7; ++i)
+        if (i < n) r = r + v[i];
+    return r;
+}
+
 __global__ void __launch_bounds__(256) predict_kernel(PredictArgs a) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.nq * a.t) return;
     const long q = e / a.t;
     const int tt = (int)(e - q * a.t);
     const long* ids = a.idx + q * a.k;
+    const double* dd = a.dist ? a.dist + q * a.k : nullptr;
+    const double* ww = a.w ? a.w + q * a.k : nullptr;
+    if (a.k <= 8) {
+        // The common case: all k indices, then all k target rows (random 8-byte gathers from
+        // L2 / Infinity Cache) and distances are requested before the first use; a loop that waits
+        // for index i, then row i, is bound by 2k memory latencies.  Same summation order as below.
+        long id[8];
+        double yv[8], wv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) id[i] = i < a.k ? ids[i] : ids[0];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            yv[i] = a.y[id[i] * a.t + tt];
+            wv[i] = a.mode == 0 ? 1.0 : (a.mode == 2 ? (i < a.k ? ww[i] : 0.0) : (i < a.k ? dd[i] : 1.0));
+        }
+        if (a.mode == 0) {
+            double acc = yv[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+                if (i < a.k) acc = acc + yv[i];
+            a.out[e] = acc / (double)a.k;
+            return;
+        }
+        if (a.mode == 1) {
+            bool any_zero = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) any_zero |= (i < a.k) && (wv[i] == 0.0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = any_zero ? (wv[i] == 0.0 ? 1.0 : 0.0) : 1.0 / wv[i];
+        }
+        double nv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nv[i] = yv[i] * wv[i];
+        a.out[e] = np_sum_small(a.k, nv) / np_sum_small(a.k, wv);
+        return;
+    }
     if (a.mode == 0) {
         // np.mean(_y[neigh_ind], axis=1): slices added in order, then one division
         double acc = a.y[ids[0] * a.t + tt];
@@ -883,8 +929,6 @@ __global__ void __launch_bounds__(256) predict_kernel(PredictArgs a) {
         a.out[e] = acc / (double)a.k;
         return;
     }
-    const double* dd = a.dist ? a.dist + q * a.k : nullptr;
-    const double* ww = a.w ? a.w + q * a.k : nullptr;
     bool any_zero = false;
     if (a.mode == 1)
         for (int i = 0; i < a.k; ++i) any_zero |= (dd[i] == 0.0);
