@@ -613,7 +613,8 @@ int coarse_list_len(int kk) { return kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16
 int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
     if (ix->ks == 2 && m_list == 6) return launch_coarse_ks<2, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 8) return launch_coarse_ks<2, 8>(ix, nq_pad, kk, st);
-    return fail(SKNNR_ERR_UNSUPPORTED, "development build: ks = 2, list lengths 6 and 8 only");
+    if (ix->ks == 2 && m_list == 16) return launch_coarse_ks<2, 16>(ix, nq_pad, kk, st);
+    return fail(SKNNR_ERR_UNSUPPORTED, "development build: ks = 2, list lengths 6, 8 and 16 only");
 }
 #else
 template <int M>
