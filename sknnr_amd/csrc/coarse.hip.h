@@ -44,13 +44,15 @@ __host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 8 :
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // Launch geometry by feature width (KS) and list length (M):
-//   light  (KS <= 2, M <= 16): 16 waves -- one 1024-thread workgroup per CU, 4 waves per SIMD at <= 128 VGPR;
-//   medium (KS 3..6, M <= 8; KS 7, M 6) : 12 waves -- 3 per SIMD at <= 170 VGPR (lo fragments fetched on demand);
-//   heavy  (the rest)        :  8 waves -- 2 per SIMD, <= 256 VGPR.
-//   Two 32-query blocks per wave while the registers allow it.
-__host__ __device__ constexpr bool coarse_is_light(int ks, int m) { return ks <= 2 && m <= 16; }
+//   light  (KS <= 2, M <= 8): 16 waves -- one 1024-thread workgroup per CU, 4 waves per SIMD at <= 128 VGPR;
+//   medium (KS 3..6, M <= 8; KS 7, M 6; KS <= 5, M 16): 12 waves -- 3 per SIMD at <= 170 VGPR
+//          (lo fragments fetched on demand);
+//   heavy  (the rest): 8 waves -- 2 per SIMD, <= 256 VGPR.
+//   Two 32-query blocks per wave while the registers allow it (measured for M = 16, KS = 2: 12 waves
+//   x 2 q-blocks is 2.2x faster than 16 waves x 1 q-block).
+__host__ __device__ constexpr bool coarse_is_light(int ks, int m) { return ks <= 2 && m <= 8; }
 __host__ __device__ constexpr bool coarse_is_medium(int ks, int m) {
-    return (ks >= 3 && ks <= 6 && m <= 8) || (ks == 7 && m <= 6);
+    return (ks >= 3 && ks <= 6 && m <= 8) || (ks == 7 && m <= 6) || (ks <= 5 && m == 16);
 }
 __host__ __device__ constexpr int coarse_waves(int ks, int m) {
     return coarse_is_light(ks, m) ? 16 : (coarse_is_medium(ks, m) ? 12 : 8);
@@ -59,7 +61,7 @@ __host__ __device__ constexpr int coarse_wps(int ks, int m) {
     return coarse_is_light(ks, m) ? 4 : (coarse_is_medium(ks, m) ? 3 : 2);
 }
 __host__ __device__ constexpr bool coarse_lo_on_demand(int ks, int m) { return coarse_is_medium(ks, m); }
-__host__ __device__ constexpr int coarse_nqb(int ks, int m) { return (ks <= 4 && m <= 8) ? 2 : 1; }
+__host__ __device__ constexpr int coarse_nqb(int ks, int m) { return ((ks <= 4 && m <= 8) || (ks <= 2 && m == 16)) ? 2 : 1; }
 
 // v_min3_f32 / v_min_f32 as raw instructions: the compiler would put a canonicalising
 // v_max in front of every fminf operand that comes out of an MFMA (16 extra VALU per tile).
