@@ -86,23 +86,43 @@ __device__ __forceinline__ float min2f(float a, float b, float dep) {
 // no accumulator operands: plain register values
 __device__ __forceinline__ float min2f(float a, float b) { return min2f(a, b, a); }
 
+#ifndef SKNNR_SHIFT_INSERT_FROM
+#define SKNNR_SHIFT_INSERT_FROM 32
+#endif
 // Sorted (ascending) insertion of (v, id) into a lane-local list whose last entry is
 // known to be > v.
 template <int M>
 __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], float v, int id) {
-    vals[M - 1] = v;
-    idxs[M - 1] = id;
+    if constexpr (M >= SKNNR_SHIFT_INSERT_FROM) {
+        // Long lists: every position decides for itself (keep / take v / take the left neighbour), high
+        // to low, so that the old left neighbour is still there.  Same result as the bubble below
+        // (v settles behind equal values); hipcc turns the 31-stage bubble of M = 32 into
+        // index-select chains (35k v_cndmask, ~100k cycles per flush).
+        bool lower_left = true;  // placeholder, set per position
 #pragma unroll
-    for (int i = M - 1; i > 0; --i) {
-        const bool sw = vals[i] < vals[i - 1];
-        const float lo = sw ? vals[i] : vals[i - 1];
-        const float hi = sw ? vals[i - 1] : vals[i];
-        const int ilo = sw ? idxs[i] : idxs[i - 1];
-        const int ihi = sw ? idxs[i - 1] : idxs[i];
-        vals[i - 1] = lo;
-        vals[i] = hi;
-        idxs[i - 1] = ilo;
-        idxs[i] = ihi;
+        for (int i = M - 1; i >= 0; --i) {
+            const bool here = v < vals[i];                              // position i changes
+            lower_left = i > 0 ? (v < vals[i - 1]) : false;              // v belongs further left
+            const float nv = lower_left ? vals[i > 0 ? i - 1 : 0] : v;
+            const int ni = lower_left ? idxs[i > 0 ? i - 1 : 0] : id;
+            vals[i] = here ? nv : vals[i];
+            idxs[i] = here ? ni : idxs[i];
+        }
+    } else {
+        vals[M - 1] = v;
+        idxs[M - 1] = id;
+#pragma unroll
+        for (int i = M - 1; i > 0; --i) {
+            const bool sw = vals[i] < vals[i - 1];
+            const float lo = sw ? vals[i] : vals[i - 1];
+            const float hi = sw ? vals[i - 1] : vals[i];
+            const int ilo = sw ? idxs[i] : idxs[i - 1];
+            const int ihi = sw ? idxs[i - 1] : idxs[i];
+            vals[i - 1] = lo;
+            vals[i] = hi;
+            idxs[i - 1] = ilo;
+            idxs[i] = ihi;
+        }
     }
 }
 

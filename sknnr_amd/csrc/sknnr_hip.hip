@@ -614,7 +614,8 @@ int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t 
     if (ix->ks == 2 && m_list == 6) return launch_coarse_ks<2, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 8) return launch_coarse_ks<2, 8>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 16) return launch_coarse_ks<2, 16>(ix, nq_pad, kk, st);
-    return fail(SKNNR_ERR_UNSUPPORTED, "development build: ks = 2, list lengths 6, 8 and 16 only");
+    if (ix->ks == 2 && m_list == 32) return launch_coarse_ks<2, 32>(ix, nq_pad, kk, st);
+    return fail(SKNNR_ERR_UNSUPPORTED, "development build: ks = 2 only");
 }
 #else
 template <int M>
