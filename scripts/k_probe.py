@@ -1,3 +1,5 @@
+#!/usr/bin/env python
+"""Development aid: throughput for n_neighbors 8..31 (16- and 32-entry lists) on the GPU box: python scripts/k_probe.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import config_probe as cp
