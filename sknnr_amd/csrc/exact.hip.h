@@ -325,16 +325,20 @@ struct FinalizeArgs {
     int* fail_count;
 };
 
-// Lane exchange inside the group of LPQ lanes that share a query.  LPQ = 16 is one DPP row: the
-// value of every other lane of the row is visited with the 15 row rotations (`row_ror:n`, a VALU
-// move with no LDS traffic and no wait); wider groups use ds_bpermute shuffles.  Only the multiset
-// of peers matters to the callers, which rotate the peer's lane number along when they need it.
+// Lane exchange inside the group of LPQ lanes that share a query.  A group is LPQ/16 DPP rows:
+// peer N = 16 b + r is reached by one ds_bpermute (lane ^ 16 b; identical calls are merged by the
+// compiler, so there is one per row block and variable) followed by the row rotation `row_ror:r`,
+// a VALU move with no LDS traffic and no wait.  N = 1 .. LPQ-1 visits every other lane of the group
+// exactly once; only the multiset of peers matters to the callers, which send the peer's lane
+// number along the same way when they need it.
 template <int LPQ, int N>
 __device__ __forceinline__ int peer_i(int v, int c) {
-    if constexpr (LPQ == 16) {
-        return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false);
+    constexpr int B = N / 16, R = N % 16;
+    const int vb = B ? __shfl_xor(v, 16 * B, LPQ) : v;
+    if constexpr (R != 0) {
+        return __builtin_amdgcn_update_dpp(0, vb, 0x120 + R, 0xf, 0xf, false);
     } else {
-        return __shfl(v, (c + N) % LPQ, LPQ);
+        return vb;
     }
 }
 template <int LPQ, int N>
@@ -351,6 +355,50 @@ template <int LPQ, int N>
 __device__ __forceinline__ double peer_d(double v, int c) {
     return __longlong_as_double(peer_l<LPQ, N>(__double_as_longlong(v), c));
 }
+// A value together with its copies from the other row blocks of the group (one ds_bpermute per
+// block, fetched once), from which peer N = 16 b + r is a DPP rotation of copy b.
+template <int LPQ>
+struct PeersI {
+    int blk[LPQ / 16];
+    __device__ __forceinline__ explicit PeersI(int v) {
+        blk[0] = v;
+#pragma unroll
+        for (int b = 1; b < LPQ / 16; ++b) blk[b] = __shfl_xor(v, 16 * b, LPQ);
+    }
+    template <int N>
+    __device__ __forceinline__ int get() const {
+        constexpr int B = N / 16, R = N % 16;
+        if constexpr (R != 0) {
+            return __builtin_amdgcn_update_dpp(0, blk[B], 0x120 + R, 0xf, 0xf, false);
+        } else {
+            return blk[B];
+        }
+    }
+};
+template <int LPQ>
+struct PeersF {
+    PeersI<LPQ> p;
+    __device__ __forceinline__ explicit PeersF(float v) : p(__float_as_int(v)) {}
+    template <int N>
+    __device__ __forceinline__ float get() const { return __int_as_float(p.template get<N>()); }
+};
+template <int LPQ>
+struct PeersL {
+    PeersI<LPQ> lo, hi;
+    __device__ __forceinline__ explicit PeersL(long v)
+        : lo((int)(unsigned)(unsigned long)v), hi((int)((unsigned long)v >> 32)) {}
+    template <int N>
+    __device__ __forceinline__ long get() const {
+        return (long)(((unsigned long)(unsigned)hi.template get<N>() << 32) | (unsigned long)(unsigned)lo.template get<N>());
+    }
+};
+template <int LPQ>
+struct PeersD {
+    PeersL<LPQ> p;
+    __device__ __forceinline__ explicit PeersD(double v) : p(__double_as_longlong(v)) {}
+    template <int N>
+    __device__ __forceinline__ double get() const { return __longlong_as_double(p.template get<N>()); }
+};
 // f(integral_constant<int, n>) for n = 1 .. LPQ-1
 template <int LPQ, int N = 1, typename F>
 __device__ __forceinline__ void for_each_peer(F&& f) {
@@ -413,9 +461,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const double eps = a.eps_c * nrm * nrm;
     const float cve = valid ? cv : INFINITY;
     int rank_c = 0;
+    const PeersI<LPQ> lane_of(c);
+    const PeersF<LPQ> cve_of(cve);
     for_each_peer<LPQ>([&](auto n) {
-        const float cj = peer_f<LPQ, n.value>(cve, c);
-        const int pj = peer_i<LPQ, n.value>(c, c);
+        const float cj = cve_of.template get<n.value>();
+        const int pj = lane_of.template get<n.value>();
         rank_c += (cj < cve) || (cj == cve && pj < c);
     });
     const double tau_c = group_min<LPQ>(rank_c >= s.kk - 1 ? (double)cve : INFINITY, c);
@@ -429,9 +479,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 
     // rank by (d2, index)
     int rank = 0, n_usable = usable ? 1 : 0;
+    const PeersD<LPQ> d2_of(d2);
+    const PeersI<LPQ> key_of(key_id);
     for_each_peer<LPQ>([&](auto n) {
-        const double dj = peer_d<LPQ, n.value>(d2, c);
-        const int ij = peer_i<LPQ, n.value>(key_id, c);
+        const double dj = d2_of.template get<n.value>();
+        const int ij = key_of.template get<n.value>();
         rank += (dj < d2) || (dj == d2 && ij < key_id);
         n_usable += dj < INFINITY;
     });
@@ -454,9 +506,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     {
         const bool mine = usable && (rank < s.kk);
         int ties = 0;
+        const PeersI<LPQ> rank_of(rank);
         for_each_peer<LPQ>([&](auto n) {
-            const double dj = peer_d<LPQ, n.value>(d2, c);
-            const int rj = peer_i<LPQ, n.value>(rank, c);
+            const double dj = d2_of.template get<n.value>();
+            const int rj = rank_of.template get<n.value>();
             if (s.deterministic) ties += (dj == d2) && mine && (rj >= s.kk);  // tie across the boundary
             else ties += (dj == d2) && mine;                                    // any tie involving a kept row
         });
@@ -487,10 +540,13 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         k1 = k1 < 0 ? -k1 : k1;
         const int tagged = key_id | (chosen ? (int)0x80000000u : 0);  // key_id >= 0: bit 31 carries `chosen`
         pos = 0;
+        const PeersD<LPQ> k0_of(k0);
+        const PeersL<LPQ> k1_of(k1);
+        const PeersI<LPQ> tag_of(tagged);
         for_each_peer<LPQ>([&](auto n) {
-            const double k0j = peer_d<LPQ, n.value>(k0, c);
-            const long k1j = peer_l<LPQ, n.value>(k1, c);
-            const int tj = peer_i<LPQ, n.value>(tagged, c);
+            const double k0j = k0_of.template get<n.value>();
+            const long k1j = k1_of.template get<n.value>();
+            const int tj = tag_of.template get<n.value>();
             const int ij = tj & 0x7fffffff;
             const bool less = (k0j < k0) || (k0j == k0 && (k1j < k1 || (k1j == k1 && ij < key_id)));
             pos += (tj < 0) && less;
