@@ -158,6 +158,27 @@ def test_larger_k(N, O, k):
     ix.close()
 
 
+@pytest.mark.parametrize("d", [20, 40, 64, 72, 96, 112, 128])   # 16-wide K-steps 2..8: light / medium / heavy geometries
+@pytest.mark.parametrize("k", [2, 6, 10, 20])                    # list lengths 6, 8, 16, 32
+def test_every_launch_geometry(N, O, d, k):
+    """Each (feature width, list length) pair selects its own workgroup shape, q-blocks per wave, LDS
+    stage size and insertion code (coarse.hip.h, launch geometry): targets and the X=None self query
+    must equal the oracle for all of them."""
+    x_ref, y, x_q = _synth(2600, 1100, d, n_dup_refs=12, n_dup_queries=8)
+    ix = N.Index(x_ref, y)
+    dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k))
+    od, oi = O.kneighbors(x_ref, x_q, k, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(dist, od)
+    dist, idx = ix.kneighbors_host(None, ix.make_opts(k, exclude_self=True), nq=2600)
+    od, oi = O.kneighbors(x_ref, None, k, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(dist, od)
+    st = ix.stats()
+    assert st["exact_only_queries"] == 0 and st["exact_fallbacks"] < 0.2 * st["queries"]
+    ix.close()
+
+
 @pytest.mark.parametrize("d", [16, 64])
 def test_larger_k_wider(N, O, d):
     x_ref, y, x_q = _synth(3000, 1500, d)
