@@ -143,8 +143,11 @@ def main():
     nq, k = args.rows, args.k
     stream = torch.cuda.current_stream()
 
-    gather_chunk = 2_500_000  # rows per all-gather: chunk i travels while chunk i+1 is computed
+    # rows per all-gather (chunk i travels while chunk i+1 is computed): 10 full rounds of the
+    # pre-filter grid (256 CUs x 1024 rows per workgroup)
+    gather_chunk = 10 * 256 * 1024
     comm_stream = torch.cuda.Stream() if use_dist else None
+    gather_in_place = [True]
 
     def step():
         if not (use_dist and not args.no_gather):
@@ -166,8 +169,16 @@ def main():
             done.record(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(done)
-                works.append(dist.all_gather_into_tensor(d_all[world * a: world * b], d_own, async_op=True))
-                works.append(dist.all_gather_into_tensor(i_all[world * a: world * b], i_own, async_op=True))
+                for whole, own in ((d_all[world * a: world * b], d_own), (i_all[world * a: world * b], i_own)):
+                    try:
+                        # in place: the send buffer is this rank's slot of the receive buffer
+                        works.append(dist.all_gather_into_tensor(whole, own if gather_in_place[0] else own.clone(),
+                                                                 async_op=True))
+                    except RuntimeError:
+                        if not gather_in_place[0]:
+                            raise
+                        gather_in_place[0] = False  # a backend that rejects aliasing: stage the slot once
+                        works.append(dist.all_gather_into_tensor(whole, own.clone(), async_op=True))
         for w in works:
             w.wait()
         torch.cuda.current_stream().wait_stream(comm_stream)
