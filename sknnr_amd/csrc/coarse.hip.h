@@ -5,23 +5,26 @@
 // Replaces the hot double loop of the reference's engine
 //   dgemm  M = -2 Xc Yc^T            SKL/metrics/_pairwise_distances_reduction/_middle_term_computer.pyx.tp:440
 //   d2 = |x|^2 + M + |y|^2, heap_push SKL/metrics/_pairwise_distances_reduction/_argkmin.pyx.tp:492-510
-// as a candidate generator; the float64 finaliser (finalize.hip.h) re-scores the
+// as a candidate generator; the float64 finaliser (exact.hip.h) re-scores the
 // candidates with the reference's exact expression and certifies the result.
 //
 // MI355X mapping
 //   * contraction on the f16 matrix pipe (v_mfma_f32_32x32x16_f16, 16x the f32 MFMA rate)
 //     with every operand split x = hi + lo (two f16 each) and three products
 //     hi.hi + lo.hi + hi.lo accumulated in f32  ->  ~2^-22 relative error, i.e. f32-class
-//     accuracy at 16/3 of the f32-MFMA throughput;
+//     accuracy at 16/3 of the f32-MFMA throughput; the two correction products are only
+//     issued for tiles in which some lane's hi.hi value is within their bound of its threshold;
 //   * references are the A operand (rows), queries the B operand (columns): the 32x32
 //     accumulator then holds ONE query per lane (col = lane & 31) and 16 references in the
 //     lane's registers, so the running top-M is lane-local (no cross-lane traffic in the
-//     sweep); lanes l and l+32 share a query and keep one list each;
+//     sweep); lanes l and l+32 share a query, keep one list each and test hits against one
+//     threshold, the (k+1)-th best value of their two lists together;
 //   * |r'|^2 enters as the C operand of the first MFMA (exact f32, no VALU add);
 //   * reference tiles are stored in HBM in MFMA-fragment order and copied to LDS by
-//     LDS-DMA (global_load_lds_dwordx4), double buffered; every wave of the 512-thread
-//     workgroup reads the same staged tile, lane-linear ds_read_b128 (conflict-free);
-//   * queries live in registers for the whole sweep (64 per wave, 512 per workgroup).
+//     LDS-DMA (global_load_lds_dwordx4), double buffered; every wave of the workgroup (16, 12
+//     or 8 waves by feature width and list length) reads the same staged tile, lane-linear
+//     ds_read_b128 (conflict-free);
+//   * queries live in registers for the whole sweep (64 or 32 per wave).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
