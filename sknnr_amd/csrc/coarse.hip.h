@@ -64,7 +64,12 @@ __host__ __device__ constexpr int coarse_wps(int ks, int m) {
     return coarse_is_light(ks, m) ? 4 : (coarse_is_medium(ks, m) ? 3 : 2);
 }
 __host__ __device__ constexpr bool coarse_lo_on_demand(int ks, int m) { return coarse_is_medium(ks, m); }
-__host__ __device__ constexpr int coarse_nqb(int ks, int m) { return ((ks <= 4 && m <= 8) || (ks <= 2 && m == 16)) ? 2 : 1; }
+#ifndef SKNNR_KS1_NQB
+#define SKNNR_KS1_NQB 3  // up to 16 features: three q-blocks per wave fit 128 VGPR (d=16, 50k refs: 11 % faster than two)
+#endif
+__host__ __device__ constexpr int coarse_nqb(int ks, int m) {
+    return (ks == 1 && m <= 8) ? SKNNR_KS1_NQB : (((ks <= 4 && m <= 8) || (ks <= 2 && m == 16)) ? 2 : 1);
+}
 
 // v_min3_f32 / v_min_f32 as raw instructions: the compiler would put a canonicalising
 // v_max in front of every fminf operand that comes out of an MFMA (16 extra VALU per tile).

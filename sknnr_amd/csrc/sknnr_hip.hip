@@ -611,6 +611,7 @@ int coarse_list_len(int kk) { return kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16
 
 #ifdef SKNNR_DEV_ONLY_KS2_M6  // development builds: only the bench's instantiation (fast compile)
 int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
+    if (ix->ks == 1 && m_list == 6) return launch_coarse_ks<1, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 6) return launch_coarse_ks<2, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 8) return launch_coarse_ks<2, 8>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 16) return launch_coarse_ks<2, 16>(ix, nq_pad, kk, st);
