@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Randomised differential test against the oracle (GPU box): random shapes, neighbour counts,
+duplicate / integer-valued data, both distance formulas, X=None, both ordering modes, affine maps.
+usage: python scripts/fuzz_parity.py [seconds] [seed]   -- exits non-zero on the first mismatch."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # noqa: F401
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402
+from sknnr_amd import _native as N  # noqa: E402
+from sknnr_amd import synth  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+n_cases = n_rows = 0
+t_report = time.time()
+while time.time() < t_end:
+    d = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 32, 33, 48, 64, 80, 100, 128]))
+    n_ref = int(rng.choice([1, 5, 31, 32, 33, 100, 257, 1000, 3000, 7000]))
+    nq = int(rng.choice([1, 31, 100, 1000, 3000]))
+    kmax = min(n_ref, 34)
+    k = int(rng.integers(1, kmax + 1))
+    kind = rng.choice(["smooth", "dup", "integer", "tiny_scale", "huge_offset"])
+    x_ref, _, x_q = synth.make_problem(max(n_ref, 2), nq, d, t=1, n_dup_refs=min(n_ref // 3, 40) if kind == "dup" else 0,
+                                       n_dup_queries=min(nq // 3, 30, max(n_ref, 2) // 2) if kind == "dup" else 0)
+    x_ref = x_ref[:n_ref]
+    y = rng.standard_normal((n_ref, 3))
+    if kind == "integer":
+        x_ref, x_q = np.round(x_ref * 2.0), np.round(x_q * 2.0)
+    elif kind == "tiny_scale":
+        x_ref, x_q = x_ref * 1e-5, x_q * 1e-5
+    elif kind == "huge_offset":
+        x_ref, x_q = x_ref + 1e4, x_q + 1e4
+    formula = int(rng.integers(0, 2))
+    fname = "expanded" if formula == 0 else "direct"
+    det = bool(rng.integers(0, 2))
+    self_query = bool(rng.integers(0, 4) == 0) and k < n_ref
+    row_offset = int(rng.choice([0, 0, 17, 123456]))
+    ix = N.Index(x_ref, y)
+    try:
+        if self_query:
+            o = ix.make_opts(k, exclude_self=True, deterministic=det, formula=formula)
+            dist, idx = ix.kneighbors_host(None, o, nq=n_ref)
+            od, oi = O.kneighbors(x_ref, None, k, fname, deterministic=det)
+        else:
+            o = ix.make_opts(k, deterministic=det, formula=formula, row_offset=row_offset)
+            dist, idx = ix.kneighbors_host(x_q, o)
+            od, oi = O.kneighbors(x_ref, x_q, k, fname, deterministic=det, row_offset=row_offset)
+        ok = np.array_equal(idx, oi) and np.array_equal(dist, od)
+        if not ok:
+            bad = np.where((idx != oi).any(axis=1) | (dist != od).any(axis=1))[0]
+            print(f"MISMATCH d={d} n_ref={n_ref} nq={nq} k={k} kind={kind} formula={fname} det={det} "
+                  f"self={self_query} row_offset={row_offset} seed={seed}: {len(bad)} rows, first {bad[:5]}")
+            r = bad[0]
+            print(" got ", idx[r], dist[r])
+            print(" want", oi[r], od[r])
+            sys.exit(1)
+        pw = ["uniform", "distance"][int(rng.integers(0, 2))]
+        if not self_query:
+            pred = ix.predict_host(x_q, ix.make_opts(k, deterministic=det, formula=formula, row_offset=row_offset,
+                                                     weight_mode=0 if pw == "uniform" else 1))
+            want = O.predict(y, od, oi, pw)
+            if not np.allclose(pred, want, rtol=1e-12, atol=0):
+                print(f"PREDICT MISMATCH d={d} n_ref={n_ref} nq={nq} k={k} kind={kind} weights={pw} seed={seed}")
+                sys.exit(1)
+    finally:
+        ix.close()
+    n_cases += 1
+    n_rows += n_ref if self_query else nq
+    if time.time() - t_report > 30:
+        print(f"... {n_cases} cases, {n_rows} query rows", flush=True)
+        t_report = time.time()
+print(f"fuzz ok: {n_cases} cases, {n_rows} query rows, seed {seed}, {budget:.0f} s")

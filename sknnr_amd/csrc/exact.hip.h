@@ -609,6 +609,21 @@ __device__ __forceinline__ void heap_push_ref(double* hv, int* hi, int k, double
     hi[cur] = id;
 }
 
+// formula 1 (the kd_tree stand-in): rows ordered by (d2, index), as oracle_argkmin_direct keeps
+// them -- a sorted list; a value equal to the current k-th is not admitted, equal values stay in
+// index order.  Unfilled slots hold DBL_MAX.
+__device__ __forceinline__ void sorted_insert_ref(double* hv, int* hi, int k, double v, int id) {
+    // caller has checked v < hv[k-1]
+    int pos = k - 1;
+    while (pos > 0 && hv[pos - 1] > v) {
+        hv[pos] = hv[pos - 1];
+        hi[pos] = hi[pos - 1];
+        --pos;
+    }
+    hv[pos] = v;
+    hi[pos] = id;
+}
+
 __device__ __forceinline__ void swap_slots(double* v, int* x, int a, int b) {
     const double tv = v[a]; v[a] = v[b]; v[b] = tv;
     const int tx = x[a]; x[a] = x[b]; x[b] = tx;
@@ -820,10 +835,13 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
                         const int bit = __builtin_ctzll(m);
                         m &= m - 1;
                         const double v = __shfl(v64, bit, 64);
-                        if (v < rt) {  // the root may have dropped since the ballot
-                            if (lane == 0) heap_push_ref(hv, hi, KK, v, j0 + 64 * u + bit);
+                        if (v < rt) {  // the bound may have dropped since the ballot
+                            if (lane == 0) {
+                                if (FORMULA == 0) heap_push_ref(hv, hi, KK, v, j0 + 64 * u + bit);
+                                else sorted_insert_ref(hv, hi, KK, v, j0 + 64 * u + bit);
+                            }
                             __builtin_amdgcn_wave_barrier();
-                            rt = hv[0];
+                            rt = FORMULA == 0 ? hv[0] : hv[KK - 1];
                         }
                     }
                 }
@@ -838,7 +856,7 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
                 const long q = a.list ? (long)a.list[f0 + qi] : f0 + qi;
                 double* hv = hv_all + qi * KK;
                 int* hi = hi_all + qi * L.kkp;
-                dual_quicksort_ref(hv, hi, KK, stack_all + qi * L.stk);
+                if (FORMULA == 0) dual_quicksort_ref(hv, hi, KK, stack_all + qi * L.stk);
                 // drop self (X=None), sqrt, reorder: serial over <= KK entries
                 const long self_id = s.row_offset + q;
                 int drop = -1;

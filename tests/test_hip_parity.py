@@ -122,7 +122,8 @@ def test_integer_features_many_exact_ties(N, O, deterministic, k):
     x_q = rng.integers(0, 4, size=(400, 6)).astype(np.float64)
     y = rng.standard_normal((1500, 3))
     ix = N.Index(x_ref, y)
-    for formula, fname in ((N.FORMULA_EXPANDED, "expanded"),):
+    # "direct" is the kd_tree stand-in: the oracle keeps tied rows in (d2, index) order there
+    for formula, fname in ((N.FORMULA_EXPANDED, "expanded"), (N.FORMULA_DIRECT, "direct")):
         dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k, formula=formula, deterministic=deterministic))
         od, oi = O.kneighbors(x_ref, x_q, k, fname, deterministic=deterministic)
         np.testing.assert_array_equal(dist, od)
