@@ -37,34 +37,63 @@ while time.time() < t_end:
         x_ref, x_q = x_ref * 1e-5, x_q * 1e-5
     elif kind == "huge_offset":
         x_ref, x_q = x_ref + 1e4, x_q + 1e4
+    x_ref_raw = x_ref
     formula = int(rng.integers(0, 2))
     fname = "expanded" if formula == 0 else "direct"
     det = bool(rng.integers(0, 2))
     self_query = bool(rng.integers(0, 4) == 0) and k < n_ref
     row_offset = int(rng.choice([0, 0, 17, 123456]))
+    # one case in three: an affine map (centre / scale / projector, d_in != d_t) applied to the
+    # references on the host entry point and fused into the query preparation kernel
+    affine = None
+    if rng.integers(0, 3) == 0 and not self_query:
+        d_t = int(rng.choice([1, 3, 8, 16, 20, 32, 40, 64]))
+        c = rng.standard_normal(d) if rng.integers(0, 2) else None
+        sc = (0.5 + rng.random(d)) if rng.integers(0, 2) else None
+        p = rng.standard_normal((d, d_t)) if rng.integers(0, 4) else None
+        affine = (c, sc, p)
+        x_raw_q = x_q
+        x_ref = N.affine_transform_host(x_ref, c, sc, p)
+        if not np.array_equal(x_ref, O.affine(x_ref_raw, c, sc, p)):
+            print(f"AFFINE MISMATCH d={d} d_t={d_t} seed={seed}")
+            sys.exit(1)
+        x_q = O.affine(x_raw_q, c, sc, p)
     ix = N.Index(x_ref, y)
     try:
+        if affine is not None:
+            ix.set_affine(d, *affine)
         if self_query:
             o = ix.make_opts(k, exclude_self=True, deterministic=det, formula=formula)
             dist, idx = ix.kneighbors_host(None, o, nq=n_ref)
             od, oi = O.kneighbors(x_ref, None, k, fname, deterministic=det)
         else:
-            o = ix.make_opts(k, deterministic=det, formula=formula, row_offset=row_offset)
-            dist, idx = ix.kneighbors_host(x_q, o)
+            o = ix.make_opts(k, deterministic=det, formula=formula, row_offset=row_offset,
+                             apply_affine=affine is not None)
+            q_in = x_raw_q if affine is not None else x_q
+            if rng.integers(0, 2):
+                dist, idx = ix.kneighbors_host(q_in, o)
+            else:  # device-resident tensors in and out
+                qd = torch.as_tensor(np.ascontiguousarray(q_in), device="cuda")
+                dd = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+                di = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+                ix.kneighbors_device(qd.data_ptr(), nq, o, dd.data_ptr(), di.data_ptr())
+                torch.cuda.synchronize()
+                dist, idx = dd.cpu().numpy(), di.cpu().numpy()
             od, oi = O.kneighbors(x_ref, x_q, k, fname, deterministic=det, row_offset=row_offset)
         ok = np.array_equal(idx, oi) and np.array_equal(dist, od)
         if not ok:
             bad = np.where((idx != oi).any(axis=1) | (dist != od).any(axis=1))[0]
             print(f"MISMATCH d={d} n_ref={n_ref} nq={nq} k={k} kind={kind} formula={fname} det={det} "
-                  f"self={self_query} row_offset={row_offset} seed={seed}: {len(bad)} rows, first {bad[:5]}")
+                  f"self={self_query} row_offset={row_offset} affine={affine is not None} seed={seed}: {len(bad)} rows, first {bad[:5]}")
             r = bad[0]
             print(" got ", idx[r], dist[r])
             print(" want", oi[r], od[r])
             sys.exit(1)
         pw = ["uniform", "distance"][int(rng.integers(0, 2))]
         if not self_query:
-            pred = ix.predict_host(x_q, ix.make_opts(k, deterministic=det, formula=formula, row_offset=row_offset,
-                                                     weight_mode=0 if pw == "uniform" else 1))
+            pred = ix.predict_host(q_in, ix.make_opts(k, deterministic=det, formula=formula, row_offset=row_offset,
+                                                      weight_mode=0 if pw == "uniform" else 1,
+                                                      apply_affine=affine is not None))
             want = O.predict(y, od, oi, pw)
             if not np.allclose(pred, want, rtol=1e-12, atol=0):
                 print(f"PREDICT MISMATCH d={d} n_ref={n_ref} nq={nq} k={k} kind={kind} weights={pw} seed={seed}")
