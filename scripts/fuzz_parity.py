@@ -16,6 +16,7 @@ from sknnr_amd import synth  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = "--big" in sys.argv  # benchmark-sized reference sets (the oracle takes seconds per case)
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 n_cases = n_rows = 0
@@ -24,6 +25,10 @@ while time.time() < t_end:
     d = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 32, 33, 48, 64, 80, 100, 128]))
     n_ref = int(rng.choice([1, 5, 31, 32, 33, 100, 257, 1000, 3000, 7000]))
     nq = int(rng.choice([1, 31, 100, 1000, 3000]))
+    if big:
+        n_ref = int(rng.choice([20000, 50000, 100003]))
+        nq = int(rng.choice([5000, 20000, 50001]))
+        d = int(rng.choice([8, 16, 32, 64]))
     kmax = min(n_ref, 34)
     k = int(rng.integers(1, kmax + 1))
     kind = rng.choice(["smooth", "dup", "integer", "tiny_scale", "huge_offset"])
@@ -102,7 +107,7 @@ while time.time() < t_end:
         ix.close()
     n_cases += 1
     n_rows += n_ref if self_query else nq
-    if time.time() - t_report > 30:
+    if big or time.time() - t_report > 30:
         print(f"... {n_cases} cases, {n_rows} query rows", flush=True)
         t_report = time.time()
 print(f"fuzz ok: {n_cases} cases, {n_rows} query rows, seed {seed}, {budget:.0f} s")
