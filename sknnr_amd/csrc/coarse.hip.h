@@ -373,37 +373,28 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
         if (st + 1 < n_stages)
             stage_copy(rimg + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
 
-#pragma unroll 1
-        for (int t = 0; t < TPS; ++t) {
-            const char* tb = cur + t * TB;
-            // The lo fragments of the tile are only needed by the correction products: with
-            // LO_ON_DEMAND (wide features, where they are 4 KS registers) they are fetched by the
-            // first q-block of the tile that is visited.
-            half8 ah[KS], al[KS];
+        // ---- one tile: (1) operands from LDS -----------------------------------------------------------
+        auto tile_load = [&](const char* tb, half8 (&ah)[KS], half8 (&al)[KS], floatx16& c0, bool keep_lo) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 ah[s] = *(const half8*)(tb + (0 * KS + s) * 1024 + lane * 16);
-                if (!LO_ON_DEMAND) al[s] = *(const half8*)(tb + (1 * KS + s) * 1024 + lane * 16);
+                if (keep_lo) al[s] = *(const half8*)(tb + (1 * KS + s) * 1024 + lane * 16);
             }
-            bool have_lo = !LO_ON_DEMAND;
-            floatx16 c0;
-            {
-                const floatx4* cp = (const floatx4*)(tb + tile_frag_bytes(KS) + half * 64);
-                const floatx4 c_0 = cp[0], c_1 = cp[1], c_2 = cp[2], c_3 = cp[3];
+            const floatx4* cp = (const floatx4*)(tb + tile_frag_bytes(KS) + half * 64);
+            const floatx4 c_0 = cp[0], c_1 = cp[1], c_2 = cp[2], c_3 = cp[3];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    c0[i] = c_0[i];
-                    c0[4 + i] = c_1[i];
-                    c0[8 + i] = c_2[i];
-                    c0[12 + i] = c_3[i];
-                }
+            for (int i = 0; i < 4; ++i) {
+                c0[i] = c_0[i];
+                c0[4 + i] = c_1[i];
+                c0[8 + i] = c_2[i];
+                c0[12 + i] = c_3[i];
             }
-            const int id_base = (st * TPS + t) * 32 + 4 * half;
-#ifdef SKNNR_COARSE_TIMERS
-            asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(c0));
-#endif
-            TSTAMP(0);  // tile operands landed in registers
-
+        };
+        // ---- (2) main products, skip tests and visits of the tile, q-block by q-block ------------------
+        // have_lo: the tile's lo fragments are in `al`; otherwise the first visit fetches them.
+        auto tile_process = [&](const char* tb, int tile_no, const floatx16& c0, half8 (&ah)[KS], half8 (&al)[KS],
+                                bool have_lo) {
+            const int id_base = tile_no * 32 + 4 * half;
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
                 __builtin_amdgcn_s_setprio(1);
@@ -423,14 +414,14 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 const float loose = thr[qb] + margin[qb];
                 CTR(0, 1);
                 if (__builtin_amdgcn_ballot_w64(m1 < loose) == 0) {
-                    TSTAMP(1);  // main product + skip test, no visit
+                    TSTAMP(1);  // skip test, no visit
                     continue;
                 }
-                TSTAMP(2);  // main product + skip test, visit follows
+                TSTAMP(2);  // skip test, visit follows
                 CTR(1, 1);
                 CTR(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(m1 < loose)));
                 CTR(12, __builtin_amdgcn_ballot_w64(m1 < thr[qb]) != 0);
-                if (LO_ON_DEMAND && !have_lo) {
+                if (!have_lo) {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) al[s] = *(const half8*)(tb + (1 * KS + s) * 1024 + lane * 16);
                     have_lo = true;
@@ -458,6 +449,16 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                     TSTAMP(4);  // flush
                 }
             }
+        };
+
+#pragma unroll 1
+        for (int t = 0; t < TPS; ++t) {
+            const char* tb = cur + t * TB;
+            half8 ah[KS], al[KS];
+            floatx16 c0;
+            tile_load(tb, ah, al, c0, !LO_ON_DEMAND);
+            TSTAMP(0);  // tile operands requested
+            tile_process(tb, st * TPS + t, c0, ah, al, !LO_ON_DEMAND);
         }
         TSTAMP(5);  // loop overhead
         __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
