@@ -68,7 +68,7 @@ __host__ __device__ constexpr bool coarse_lo_on_demand(int ks, int m) { return c
 #define SKNNR_KS1_NQB 3  // up to 16 features: three q-blocks per wave fit 128 VGPR (d=16, 50k refs: 11 % faster than two)
 #endif
 __host__ __device__ constexpr int coarse_nqb(int ks, int m) {
-    return (ks == 1 && m <= 8) ? SKNNR_KS1_NQB : (((ks <= 4 && m <= 8) || (ks <= 2 && m == 16)) ? 2 : 1);
+    return (ks == 1 && m <= 6) ? SKNNR_KS1_NQB : (((ks <= 4 && m <= 8) || (ks <= 2 && m == 16)) ? 2 : 1);
 }
 
 // v_min3_f32 / v_min_f32 as raw instructions: the compiler would put a canonicalising
