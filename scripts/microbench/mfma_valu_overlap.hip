@@ -2,7 +2,7 @@
 // the same SIMD?  Workgroups of 8 waves (2 per SIMD), one workgroup per CU.  mode 0: all waves issue
 // dependent MFMA chains; mode 1: all waves issue v_min3 chains; mode 2: waves 0-3 MFMA, waves 4-7
 // VALU (SIMD partners do different work); mode 3: every wave alternates MFMA and VALU bursts.
-// build: hipcc --offload-arch=gfx950 -O3 mfma_valu_overlap.hip -o mfma_valu_overlap
+// build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-result scripts/microbench/mfma_valu_overlap.hip -o scripts/microbench/mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
