@@ -106,11 +106,10 @@ __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], fl
         // to low, so that the old left neighbour is still there.  Same result as the bubble below
         // (v settles behind equal values); hipcc turns the 31-stage bubble of M = 32 into
         // index-select chains (35k v_cndmask, ~100k cycles per flush).
-        bool lower_left = true;  // placeholder, set per position
 #pragma unroll
         for (int i = M - 1; i >= 0; --i) {
-            const bool here = v < vals[i];                              // position i changes
-            lower_left = i > 0 ? (v < vals[i - 1]) : false;              // v belongs further left
+            const bool here = v < vals[i];                                    // position i changes
+            const bool lower_left = i > 0 ? (v < vals[i - 1]) : false;        // v belongs further left
             const float nv = lower_left ? vals[i > 0 ? i - 1 : 0] : v;
             const int ni = lower_left ? idxs[i > 0 ? i - 1 : 0] : id;
             vals[i] = here ? nv : vals[i];
