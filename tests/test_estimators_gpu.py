@@ -269,3 +269,39 @@ def test_k_too_large_is_a_value_error(E, moscow):
         est.kneighbors(moscow["X_test"], n_neighbors=7)
     with pytest.raises(NotImplementedError, match="Euclidean"):
         E.RawKNNRegressor(metric="manhattan").fit(moscow["X_train"], moscow["y_train"])
+
+
+def test_sharded_single_rank_over_rccl(E, moscow):
+    """The N > 1 machinery with one rank on the real backend (nccl = RCCL): contiguous shards and
+    the chunk-cyclic in-place gather both reproduce the plain call, raw and transformed."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from sknnr_amd.distributed import ShardedKNN
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    except Exception as err:  # no usable RCCL in this environment: nothing of ours to test
+        pytest.skip(f"RCCL process group could not be created: {err}")
+    try:
+        for cls in (E.RawKNNRegressor, E.GNNRegressor):
+            est = cls(n_neighbors=3).fit(moscow["X_train"], moscow["y_train"])
+            x = np.tile(moscow["X_test"], (40, 1))           # 1320 rows
+            want_d, want_i = est.kneighbors(x)
+            sh = ShardedKNN(est)
+            got_d, got_i = sh.kneighbors(x)
+            np.testing.assert_array_equal(got_i, want_i)
+            np.testing.assert_array_equal(got_d, want_d)
+            xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device="cuda")
+            cd, ci = sh.kneighbors_cyclic(xt, chunk_rows=500)   # 3 chunks, the last one ragged
+            np.testing.assert_array_equal(ci.cpu().numpy(), want_i)
+            np.testing.assert_array_equal(cd.cpu().numpy(), want_d)
+    finally:
+        dist.destroy_process_group()
