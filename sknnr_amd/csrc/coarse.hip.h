@@ -64,11 +64,17 @@ __host__ __device__ constexpr int coarse_wps(int ks, int m) {
     return coarse_is_light(ks, m) ? 4 : (coarse_is_medium(ks, m) ? 3 : 2);
 }
 __host__ __device__ constexpr bool coarse_lo_on_demand(int ks, int m) { return coarse_is_medium(ks, m); }
+#ifndef SKNNR_M2_NQB
+#define SKNNR_M2_NQB 4  // one neighbour (lists of 2): four q-blocks per wave up to 16 features, three up to 32
+#endif
+#ifndef SKNNR_M2_KS2_NQB
+#define SKNNR_M2_KS2_NQB 3
+#endif
 #ifndef SKNNR_KS1_NQB
 #define SKNNR_KS1_NQB 3  // up to 16 features: three q-blocks per wave fit 128 VGPR (d=16, 50k refs: 11 % faster than two)
 #endif
 __host__ __device__ constexpr int coarse_nqb(int ks, int m) {
-    return (ks == 1 && m <= 6) ? SKNNR_KS1_NQB : (((ks <= 4 && m <= 8) || (ks <= 2 && m == 16)) ? 2 : 1);
+    return (m == 2 && ks == 1) ? SKNNR_M2_NQB : (m == 2 && ks == 2) ? SKNNR_M2_KS2_NQB : (ks == 1 && m <= 6) ? SKNNR_KS1_NQB : (((ks <= 4 && m <= 8) || (ks <= 2 && m == 16)) ? 2 : 1);
 }
 
 // v_min3_f32 / v_min_f32 as raw instructions: the compiler would put a canonicalising
@@ -133,7 +139,7 @@ __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], fl
     }
 }
 
-// Candidate queue of one lane: kQueueCap (value, index) pairs in LDS, laid out
+// Candidate queue of one lane: queue_cap(M) (value, index) pairs in LDS, laid out
 // [entry][lane] so that the batched flush reads conflict-free.  A hit is appended with a
 // handful of instructions; the 44-instruction sorted insertion runs later, for all lanes of
 // the wave at once (the flush), instead of once per hit with one or two lanes active.
@@ -161,9 +167,10 @@ __device__ unsigned long long coarse_counters[16];
 #define SKNNR_PRIO_SCAN 2
 #endif
 
-constexpr int kQueueCap = 4;
-constexpr int kQueueFlushAt = 3;
-__host__ __device__ constexpr int queue_bytes_per_wave(int nqb) { return nqb * kQueueCap * 64 * 8; }
+// 4 deep, flushed at 3; the 2-entry lists (one neighbour, four q-blocks per wave) make do with 2
+__host__ __device__ constexpr int queue_cap(int m) { return m == 2 ? 2 : 4; }
+__host__ __device__ constexpr int queue_flush_at(int m) { return m == 2 ? 2 : 3; }
+__host__ __device__ constexpr int queue_bytes_per_wave(int nqb, int m) { return nqb * queue_cap(m) * 64 * 8; }
 
 // The three-product split contraction of one 32-ref x 32-query tile, in two stages:
 //   main    = |r'|^2 + hi.hi                     (KS MFMAs)
@@ -236,7 +243,7 @@ __device__ __forceinline__ void take_hit(float v, int id, float (&vals)[M], int 
     if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
     CTR(3, 1);
     CTR(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(hit)));
-    const bool room = cnt < kQueueCap;
+    const bool room = cnt < queue_cap(M);
     if (hit && room) {
         queue_store(qlane + cnt * 512, v, id);
         cnt += 1;
@@ -285,7 +292,7 @@ __device__ __forceinline__ void flush_queue(float (&vals)[M], int (&idxs)[M], fl
 }
 
 // KS : 16-wide K-steps per split part (padded feature count / 16)
-// M  : list length per lane (6, 8, 16 or 32: up to 5, 7, 15 or 31 neighbours searched)
+// M  : list length per lane (2, 6, 8, 16 or 32: up to 1, 5, 7, 15 or 31 neighbours searched)
 template <int KS, int M>
 __global__ void __launch_bounds__(coarse_waves(KS, M) * 64, coarse_wps(KS, M))
 coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
@@ -308,7 +315,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
     constexpr int NQB = coarse_nqb(KS, M);
     constexpr bool LO_ON_DEMAND = coarse_lo_on_demand(KS, M);
     const int qb0 = (blockIdx.x * WAVES + wave) * NQB;
-    const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue_bytes_per_wave(NQB) + lane * 8);
+    const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue_bytes_per_wave(NQB, M) + lane * 8);
 
     // Queries of this wave: B fragments, resident for the whole sweep.
     half8 bh[NQB][KS], bl[NQB][KS];
@@ -428,7 +435,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 __builtin_amdgcn_s_setprio(SKNNR_PRIO_CORR);
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
                 __builtin_amdgcn_s_setprio(SKNNR_PRIO_SCAN);
-                const unsigned qlane = qwave + qb * (kQueueCap * 512);
+                const unsigned qlane = qwave + qb * (queue_cap(M) * 512);
                 // (take_hit's compare is compiler-visible: it is the hazard-padded first reader of the
                 // corrected accumulator)
 #pragma unroll
@@ -442,7 +449,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                 }
                 __builtin_amdgcn_s_setprio(0);
                 TSTAMP(3);  // corrections + hit scan
-                if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) {
+                if (__builtin_amdgcn_ballot_w64(cnt[qb] >= queue_flush_at(M)) != 0) {
                     CTR(6, 1);
                     flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qlane CTR_PASS);
                     TSTAMP(4);  // flush
@@ -466,7 +473,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-        flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qwave + qb * (kQueueCap * 512) CTR_PASS);
+        flush_queue<M>(vals[qb], idxs[qb], thr[qb], cnt[qb], qwave + qb * (queue_cap(M) * 512) CTR_PASS);
         const size_t q = (size_t)(qb0 + qb) * 32 + (lane & 31);
         const size_t base = (q * 2 + half) * M;
 #pragma unroll

@@ -116,7 +116,7 @@ struct DevBuf {
 };
 
 constexpr int kMaxKs = 8;              // coarse path: d <= 128
-constexpr long kRowQuantum = 3072;  // query-row padding: multiple of every coarse geometry (1024, 768, 512, 256 rows per workgroup)
+constexpr long kRowQuantum = 6144;  // query-row padding: multiple of every coarse geometry (2048, 1536, 1024, 768, 512, 384, 256 rows per workgroup)
 constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk (each chunk is padded to kRowQuantum)
 constexpr int kScanMaxKK = 192;
 // Error budget of the split contraction, in units of 2^-24 (|q'| + max|r'|)^2:
@@ -592,7 +592,7 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
     constexpr int WAVES = coarse_waves(KS, M);
     constexpr int QPB = WAVES * NQB * 32;
     constexpr int TPS = tiles_per_stage(KS);
-    constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS) + (size_t)WAVES * queue_bytes_per_wave(NQB);
+    constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS) + (size_t)WAVES * queue_bytes_per_wave(NQB, M);
     static_assert(kRowQuantum % QPB == 0, "query rows are padded to multiples of kRowQuantum");
     static_assert(sh <= 160 * 1024, "LDS budget");
     auto kern = coarse_kernel<KS, M>;
@@ -607,11 +607,13 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
 // List length per lane for kk neighbours searched: at least one spare slot keeps the certificate
 // cheap.  kk > 31 is outside the MFMA envelope (exact scan for the whole call).
 constexpr int kCoarseMaxKK = 31;
-int coarse_list_len(int kk) { return kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32)); }
+int coarse_list_len(int kk) { return kk <= 1 ? 2 : (kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32))); }
 
 #ifdef SKNNR_DEV_ONLY_KS2_M6  // development builds: only the bench's instantiation (fast compile)
 int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
     if (ix->ks == 1 && m_list == 6) return launch_coarse_ks<1, 6>(ix, nq_pad, kk, st);
+    if (ix->ks == 1 && m_list == 2) return launch_coarse_ks<1, 2>(ix, nq_pad, kk, st);
+    if (ix->ks == 2 && m_list == 2) return launch_coarse_ks<2, 2>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 6) return launch_coarse_ks<2, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 8) return launch_coarse_ks<2, 8>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 16) return launch_coarse_ks<2, 16>(ix, nq_pad, kk, st);
@@ -636,6 +638,7 @@ int launch_coarse_m(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
 
 int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
     switch (m_list) {
+        case 2: return launch_coarse_m<2>(ix, nq_pad, kk, st);
         case 6: return launch_coarse_m<6>(ix, nq_pad, kk, st);
         case 8: return launch_coarse_m<8>(ix, nq_pad, kk, st);
         case 16: return launch_coarse_m<16>(ix, nq_pad, kk, st);
