@@ -143,9 +143,17 @@ def main():
     nq, k = args.rows, args.k
     stream = torch.cuda.current_stream()
 
-    # rows per all-gather (chunk i travels while chunk i+1 is computed): 10 full rounds of the
-    # pre-filter grid (256 CUs x 1024 rows per workgroup)
-    gather_chunk = 10 * 256 * 1024
+    # N > 1: four all-gather chunks (chunk i travels while chunk i+1 is computed), cut at whole rounds
+    # of the pre-filter grid (256 CUs x 1024 rows per workgroup) and shrinking, so that the last
+    # gather -- the only one nothing hides -- is the smallest
+    round_rows = 256 * 1024
+    n_rounds = -(-args.rows // round_rows)
+    cuts, acc_w = [0], 0.0
+    for w_ in (0.31, 0.28, 0.23):
+        acc_w += w_
+        cuts.append(min(args.rows, max(cuts[-1], int(round(acc_w * n_rounds)) * round_rows)))
+    cuts.append(args.rows)
+    gather_chunks = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
     comm_stream = torch.cuda.Stream() if use_dist else None
     gather_in_place = [True]
 
@@ -160,8 +168,7 @@ def main():
         d_all = torch.empty((world * nq, k), dtype=torch.float64, device="cuda")
         i_all = torch.empty((world * nq, k), dtype=torch.int64, device="cuda")
         works = []
-        for a in range(0, nq, gather_chunk):
-            b = min(nq, a + gather_chunk)
+        for a, b in gather_chunks:
             lo = cyclic_slot(world, rank, a, b)
             d_own, i_own = d_all[lo: lo + (b - a)], i_all[lo: lo + (b - a)]
             eng.kneighbors(q[a:b], k, apply_affine=True, deterministic=True, row_offset=lo, out=(d_own, i_own))
