@@ -498,8 +498,8 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 // written out.  One wave per (32-ref tile, 32-query block).
 template <int KS>
 __global__ void __launch_bounds__(64)
-coarse_matrix_kernel(const char* __restrict__ rimg, const uint4* __restrict__ qimg, int n_ref,
-                     int nq, float* __restrict__ out) {
+coarse_matrix_kernel(const char* __restrict__ rimg, const int* __restrict__ perm, const uint4* __restrict__ qimg,
+                     int n_ref, int nq, float* __restrict__ out) {
     const int lane = threadIdx.x;
     const int tile = blockIdx.x, qblk = blockIdx.y;
     const char* tb = rimg + (size_t)tile * tile_bytes(KS);
@@ -520,8 +520,8 @@ coarse_matrix_kernel(const char* __restrict__ rimg, const uint4* __restrict__ qi
     const int q = qblk * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int ref = tile * 32 + acc_row(r, half);
-        if (q < nq && ref < n_ref) out[(size_t)q * n_ref + ref] = acc[r];
+        const int pos = tile * 32 + acc_row(r, half);
+        if (q < nq && pos < n_ref) out[(size_t)q * n_ref + perm[pos]] = acc[r];
     }
 }
 

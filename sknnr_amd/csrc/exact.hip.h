@@ -314,7 +314,8 @@ __device__ __forceinline__ double round_key(double x, double p10, int divisor) {
 struct FinalizeArgs {
     SelectArgs s;
     const float* cand_val;  // [nq][2][m_list]
-    const int* cand_idx;
+    const int* cand_idx;    // image positions (coarse.hip.h sweeps the norm-ordered image)
+    const int* perm;        // image position -> reference row
     int m_list;             // entries per lane list written by the coarse kernel (<= M)
     const double* qnc;      // (nq)
     double inv_s2;          // 1 / s^2
@@ -449,9 +450,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const int list = c / M, slot = c % M;
     const bool has_slot = slot < a.m_list;
     const long cpos = (q * 2 + list) * a.m_list + (has_slot ? slot : 0);
-    const int id = has_slot ? a.cand_idx[cpos] : -1;
+    const int pos_img = has_slot ? a.cand_idx[cpos] : -1;
     const float cv = has_slot ? a.cand_val[cpos] : INFINITY;
-    const bool valid = id >= 0 && id < s.n_ref;
+    const bool valid = pos_img >= 0 && pos_img < s.n_ref;
+    const int id = valid ? a.perm[pos_img] : -1;
 
     // Only candidates whose pre-filter value is within 2 eps of the kk-th smallest one can be
     // among the kk nearest (or tie with them); the others are strictly farther than kk

@@ -148,6 +148,7 @@ struct sknnr_index {
 
     DevBuf<double> ref64, refT, rn64, y64, mu_dev;  // refT: (d, n_ref) transposed copy for the exact scan
     DevBuf<char> rimg;
+    DevBuf<int> perm;  // image position -> reference row (rows are imaged by increasing centred norm)
 
     // workspace (one chunk)
     DevBuf<double> xt, qnc, xstage, dist_stage, pred_stage;
@@ -181,6 +182,7 @@ struct sknnr_index {
                         &dist_stage, &pred_stage})
             b->release();
         rimg.release();
+        perm.release();
         qimg.release();
         cand_val.release();
         cand_idx.release();
@@ -300,6 +302,24 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         ix->s = std::ldexp(1.0, e);
         const double s = ix->s;
 
+        // Image order: reference rows by increasing centred norm.  A row near the centre of the data is,
+        // on average, closer to every query than a far one (d2 = |q'|^2 + |r'|^2 - 2 q'.r'), so the lists
+        // fill with good candidates early and later tiles are visited less often (simulated on the
+        // benchmark law: 31.6 % -> 24.6 % of the tile x q-block tests).  `perm` maps an image position
+        // back to the caller's row index; only the finaliser needs it.
+        std::vector<double> cnorm((size_t)n_ref);
+        for (int64_t i = 0; i < n_ref; ++i) {
+            double yn = 0.0;
+            for (int c = 0; c < d; ++c) {
+                const double b = s * (ref[i * d + c] - ix->mu[c]);
+                yn += b * b;
+            }
+            cnorm[(size_t)i] = yn;
+        }
+        std::vector<int> perm((size_t)n_ref);
+        for (int64_t i = 0; i < n_ref; ++i) perm[(size_t)i] = (int)i;
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return cnorm[(size_t)a] < cnorm[(size_t)b]; });
+
         const int tps = tiles_per_stage(ks);
         const long n_tiles = ((n_ref + 31) / 32 + tps - 1) / tps * tps;
         ix->n_stages = (int)(n_tiles / tps);
@@ -312,11 +332,12 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
             for (int part = 0; part < 2; ++part)
                 for (int step = 0; step < ks; ++step)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const long row = tile * 32 + (lane & 31);
+                        const long pos = tile * 32 + (lane & 31);
+                        const long row = pos < n_ref ? perm[(size_t)pos] : -1;
                         for (int j = 0; j < 8; ++j) {
                             const int k = step * 16 + 8 * (lane >> 5) + j;
                             double a = 0.0;
-                            if (row < n_ref && k < d) a = -2.0 * s * (ref[row * d + k] - ix->mu[k]);
+                            if (row >= 0 && k < d) a = -2.0 * s * (ref[row * d + k] - ix->mu[k]);
                             const uint16_t hi = f64_to_f16_bits(a);
                             uint16_t bits = hi;
                             if (part == 1) bits = f64_to_f16_bits(a - f16_bits_to_f64(hi));
@@ -326,14 +347,10 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
             float* ci = reinterpret_cast<float*>(rec + tile_frag_bytes(ks));
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r) {
-                    const long row = tile * 32 + acc_row(r, h);
+                    const long pos = tile * 32 + acc_row(r, h);
                     float v = std::numeric_limits<float>::infinity();
-                    if (row < n_ref) {
-                        double yn = 0.0;
-                        for (int c = 0; c < d; ++c) {
-                            const double b = s * (ref[row * d + c] - ix->mu[c]);
-                            yn += b * b;
-                        }
+                    if (pos < n_ref) {
+                        const double yn = cnorm[(size_t)perm[(size_t)pos]];
                         ymax2 = std::max(ymax2, yn);
                         v = (float)yn;
                     }
@@ -343,6 +360,8 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         ix->ymax = std::sqrt(ymax2);
         HIP_TRY(ix->rimg.ensure(img.size()));
         HIP_TRY(hipMemcpy(ix->rimg.p, img.data(), img.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ix->perm.ensure((size_t)n_ref));
+        HIP_TRY(hipMemcpy(ix->perm.p, perm.data(), (size_t)n_ref * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY(ix->mu_dev.ensure(dp));
         HIP_TRY(hipMemcpy(ix->mu_dev.p, ix->mu.data(), dp * sizeof(double), hipMemcpyHostToDevice));
     }
@@ -797,6 +816,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         f.s.out_idx = d_idx + c0 * o->n_neighbors;
         f.cand_val = ix->cand_val.p;
         f.cand_idx = ix->cand_idx.p;
+        f.perm = ix->perm.p;
         f.qnc = ix->qnc.p;
         f.m_list = coarse_list_len(kk);
         f.inv_s2 = 1.0 / (ix->s * ix->s);
@@ -1175,7 +1195,7 @@ extern "C" int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int6
 // ----------------------------------------------------------------------------------------
 template <int KS>
 static void launch_matrix(sknnr_index* ix, long n_tiles, long nqb, long nq, float* out) {
-    coarse_matrix_kernel<KS><<<dim3((unsigned)n_tiles, (unsigned)nqb), dim3(64)>>>(ix->rimg.p, ix->qimg.p, (int)ix->n_ref, (int)nq, out);
+    coarse_matrix_kernel<KS><<<dim3((unsigned)n_tiles, (unsigned)nqb), dim3(64)>>>(ix->rimg.p, ix->perm.p, ix->qimg.p, (int)ix->n_ref, (int)nq, out);
 }
 
 extern "C" int sknnr_debug_coarse_matrix(sknnr_index* ix, const double* q, int64_t nq, float* out, double* out_qnorm,
