@@ -235,6 +235,63 @@ extern "C" int sknnr_index_shape(const sknnr_index* ix, int64_t* n_ref, int32_t*
 // ----------------------------------------------------------------------------------------
 // index construction
 // ----------------------------------------------------------------------------------------
+// Decide the order of the reference image by replaying the pre-filter's visit rule on a sample:
+// 64 pseudo-queries (a sampled row displaced by 0.35 x the difference of two others) sweep up to
+// 8192 sampled rows in tiles of 32, once in the caller's order and once by increasing centred norm,
+// keeping the 6 best per query; the order with fewer visited (tile, 32-query block) pairs wins, the
+// norm order only by a clear margin.
+static bool image_order_by_norm(const double* ref, int64_t n_ref, int d, const std::vector<double>& cnorm) {
+    if (std::getenv("SKNNR_IMAGE_ORDER")) return std::atoi(std::getenv("SKNNR_IMAGE_ORDER")) != 0;
+    if (n_ref < 2048) return false;
+    const int S = (int)std::min<int64_t>(n_ref, 8192), NQ = 64, J = 6;
+    const int64_t stride = n_ref / S;
+    std::vector<int> sample(S);
+    for (int i = 0; i < S; ++i) sample[i] = (int)(i * stride);
+    std::vector<int> by_norm(sample);
+    std::stable_sort(by_norm.begin(), by_norm.end(), [&](int a, int b) { return cnorm[(size_t)a] < cnorm[(size_t)b]; });
+    // pseudo-queries
+    std::vector<double> q((size_t)NQ * d);
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (int64_t)(rng % (uint64_t)n_ref); };
+    for (int i = 0; i < NQ; ++i) {
+        const int64_t a = next(), b = next(), c = next();
+        for (int k = 0; k < d; ++k) q[(size_t)i * d + k] = ref[a * d + k] + 0.35 * (ref[b * d + k] - ref[c * d + k]);
+    }
+    auto visits = [&](const std::vector<int>& order) {
+        std::vector<double> best((size_t)NQ * J, std::numeric_limits<double>::infinity());
+        long n_vis = 0;
+        for (int t0 = 0; t0 + 32 <= S; t0 += 32) {
+            for (int qb = 0; qb < NQ / 32; ++qb) {
+                bool any = false;
+                for (int qi = qb * 32; qi < qb * 32 + 32; ++qi) {
+                    double* bq = &best[(size_t)qi * J];
+                    const double thr = bq[J - 1];  // threshold as of the start of the tile, like the kernel's
+                    for (int r = t0; r < t0 + 32; ++r) {
+                        const double* rr = ref + (int64_t)order[r] * d;
+                        double d2 = 0.0;
+                        for (int k = 0; k < d; ++k) {
+                            const double t = q[(size_t)qi * d + k] - rr[k];
+                            d2 += t * t;
+                        }
+                        if (d2 < thr) {
+                            any = true;
+                            if (d2 < bq[J - 1]) {
+                                int p = J - 1;
+                                while (p > 0 && bq[p - 1] > d2) { bq[p] = bq[p - 1]; --p; }
+                                bq[p] = d2;
+                            }
+                        }
+                    }
+                }
+                n_vis += any;
+            }
+        }
+        return n_vis;
+    };
+    const long v_orig = visits(sample), v_norm = visits(by_norm);
+    return v_norm * 100 < v_orig * 93;
+}
+
 extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, const double* y,
                                   int32_t t, int32_t device, sknnr_index** out) {
     if (!out) return fail(SKNNR_ERR_INVALID, "out is NULL");
@@ -302,11 +359,14 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         ix->s = std::ldexp(1.0, e);
         const double s = ix->s;
 
-        // Image order: reference rows by increasing centred norm.  A row near the centre of the data is,
-        // on average, closer to every query than a far one (d2 = |q'|^2 + |r'|^2 - 2 q'.r'), so the lists
-        // fill with good candidates early and later tiles are visited less often (simulated on the
-        // benchmark law: 31.6 % -> 24.6 % of the tile x q-block tests).  `perm` maps an image position
-        // back to the caller's row index; only the finaliser needs it.
+        // Image order: the caller's, or reference rows by increasing centred norm.  In a high-dimensional
+        // cloud a row near the centre is, on average, closer to every query than a far one
+        // (d2 = |q'|^2 + |r'|^2 - 2 q'.r'): the lists fill with good candidates early and later tiles
+        // are visited less often (benchmark law, 32-D: 31.6 % -> 24.6 % of the tile x q-block tests;
+        // 10M x 50k x 64: 83 -> 101 Mq/s).  In few dimensions the norms spread widely and the centre
+        // rows are poor candidates for most queries (8-D, 100k rows: 193 -> 148 Mq/s), so the choice is
+        // made per index by replaying both orders on a sample (image_order_by_norm).  `perm` maps an
+        // image position back to the caller's row index; only the finaliser needs it.
         std::vector<double> cnorm((size_t)n_ref);
         for (int64_t i = 0; i < n_ref; ++i) {
             double yn = 0.0;
@@ -318,7 +378,8 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         }
         std::vector<int> perm((size_t)n_ref);
         for (int64_t i = 0; i < n_ref; ++i) perm[(size_t)i] = (int)i;
-        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return cnorm[(size_t)a] < cnorm[(size_t)b]; });
+        if (image_order_by_norm(ref, n_ref, d, cnorm))
+            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return cnorm[(size_t)a] < cnorm[(size_t)b]; });
 
         const int tps = tiles_per_stage(ks);
         const long n_tiles = ((n_ref + 31) / 32 + tps - 1) / tps * tps;
