@@ -180,6 +180,26 @@ def test_every_launch_geometry(N, O, d, k):
     ix.close()
 
 
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_reference_image_order_does_not_change_results(N, O, monkeypatch, order):
+    """The pre-filter sweeps the references in the caller's order or by increasing centred norm
+    (chosen per index; SKNNR_IMAGE_ORDER pins it): candidates are mapped back to row indices, so the
+    answers -- ties, X=None, row offsets included -- are the same either way."""
+    monkeypatch.setenv("SKNNR_IMAGE_ORDER", order)
+    x_ref, y, x_q = _synth(3100, 900, 24, n_dup_refs=40, n_dup_queries=20)
+    ix = N.Index(x_ref, y)
+    for k in (1, 5, 7):
+        dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k, row_offset=1000))
+        od, oi = O.kneighbors(x_ref, x_q, k, "expanded", row_offset=1000)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+    dist, idx = ix.kneighbors_host(None, ix.make_opts(4, exclude_self=True), nq=3100)
+    od, oi = O.kneighbors(x_ref, None, 4, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(dist, od)
+    ix.close()
+
+
 @pytest.mark.parametrize("d", [16, 64])
 def test_larger_k_wider(N, O, d):
     x_ref, y, x_q = _synth(3000, 1500, d)
