@@ -238,11 +238,14 @@ extern "C" int sknnr_index_shape(const sknnr_index* ix, int64_t* n_ref, int32_t*
 // Decide the order of the reference image by replaying the pre-filter's visit rule on a sample:
 // 64 pseudo-queries (a sampled row displaced by 0.35 x the difference of two others) sweep up to
 // 8192 sampled rows in tiles of 32, once in the caller's order and once by increasing centred norm,
-// keeping the 6 best per query; the order with fewer visited (tile, 32-query block) pairs wins, the
-// norm order only by a clear margin.
-static bool image_order_by_norm(const double* ref, int64_t n_ref, int d, const std::vector<double>& cnorm) {
-    if (std::getenv("SKNNR_IMAGE_ORDER")) return std::atoi(std::getenv("SKNNR_IMAGE_ORDER")) != 0;
-    if (n_ref < 2048) return false;
+// keeping the 6 best per query; the order with fewer visited (tile, 32-query block) pairs wins, an
+// order other than the caller's only by a clear margin.
+// returns 0: the caller's order, 1: increasing centred norm, 2: a fixed pseudo-random shuffle (for callers
+// whose rows are sorted by something that correlates with the features: the first tiles would then
+// cover one corner of the cloud only)
+static int choose_image_order(const double* ref, int64_t n_ref, int d, const std::vector<double>& cnorm) {
+    if (std::getenv("SKNNR_IMAGE_ORDER")) return std::atoi(std::getenv("SKNNR_IMAGE_ORDER"));
+    if (n_ref < 2048) return 0;
     const int S = (int)std::min<int64_t>(n_ref, 8192), NQ = 64, J = 6;
     const int64_t stride = n_ref / S;
     std::vector<int> sample(S);
@@ -288,8 +291,22 @@ static bool image_order_by_norm(const double* ref, int64_t n_ref, int d, const s
         }
         return n_vis;
     };
-    const long v_orig = visits(sample), v_norm = visits(by_norm);
-    return v_norm * 100 < v_orig * 93;
+    // the sample in a fixed pseudo-random order (a strided walk is already spread over the rows; the
+    // shuffle removes what is left of the caller's ordering)
+    std::vector<int> shuffled(sample);
+    for (int i = S - 1; i > 0; --i) {
+        rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+        std::swap(shuffled[i], shuffled[(int)(rng % (uint64_t)(i + 1))]);
+    }
+    // caller's order on CONSECUTIVE rows (what the image would really hold tile by tile)
+    std::vector<int> head(S);
+    for (int i = 0; i < S; ++i) head[i] = i;
+    const long v_orig = std::max(visits(sample), visits(head)), v_norm = visits(by_norm), v_shuf = visits(shuffled);
+    long best = v_orig;
+    int choice = 0;
+    if (v_shuf * 100 < best * 93) { best = v_shuf; choice = 2; }
+    if (v_norm * 100 < best * 93) { best = v_norm; choice = 1; }
+    return choice;
 }
 
 extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, const double* y,
@@ -365,7 +382,7 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         // are visited less often (benchmark law, 32-D: 31.6 % -> 24.6 % of the tile x q-block tests;
         // 10M x 50k x 64: 83 -> 101 Mq/s).  In few dimensions the norms spread widely and the centre
         // rows are poor candidates for most queries (8-D, 100k rows: 193 -> 148 Mq/s), so the choice is
-        // made per index by replaying both orders on a sample (image_order_by_norm).  `perm` maps an
+        // made per index by replaying the candidate orders on a sample (choose_image_order).  `perm` maps an
         // image position back to the caller's row index; only the finaliser needs it.
         std::vector<double> cnorm((size_t)n_ref);
         for (int64_t i = 0; i < n_ref; ++i) {
@@ -378,8 +395,16 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         }
         std::vector<int> perm((size_t)n_ref);
         for (int64_t i = 0; i < n_ref; ++i) perm[(size_t)i] = (int)i;
-        if (image_order_by_norm(ref, n_ref, d, cnorm))
+        const int image_order = choose_image_order(ref, n_ref, d, cnorm);
+        if (image_order == 1) {
             std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return cnorm[(size_t)a] < cnorm[(size_t)b]; });
+        } else if (image_order == 2) {
+            uint64_t rs = 0xD1B54A32D192ED03ull;
+            for (int64_t i = n_ref - 1; i > 0; --i) {
+                rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+                std::swap(perm[(size_t)i], perm[(size_t)(rs % (uint64_t)(i + 1))]);
+            }
+        }
 
         const int tps = tiles_per_stage(ks);
         const long n_tiles = ((n_ref + 31) / 32 + tps - 1) / tps * tps;
