@@ -180,7 +180,7 @@ def test_every_launch_geometry(N, O, d, k):
     ix.close()
 
 
-@pytest.mark.parametrize("order", ["0", "1", "2"])
+@pytest.mark.parametrize("order", ["0", "1", "2", "3"])
 def test_reference_image_order_does_not_change_results(N, O, monkeypatch, order):
     """The pre-filter sweeps the references in the caller's order or by increasing centred norm
     (chosen per index; SKNNR_IMAGE_ORDER pins it): candidates are mapped back to row indices, so the
