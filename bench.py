@@ -8,13 +8,21 @@ One "step" = one ``kneighbors`` pass of the transformed estimator path over one 
 synthetic query rows already resident in HBM:
     affine transform (32 -> 32, the GNN/CCA form)  ->  f16x3 MFMA pre-filter over all
     references  ->  float64 re-score + certificate + sknnr reorder  ->  (dist, idx) in HBM,
-and, with N > 1, the RCCL all-gather of the per-rank (dist, idx) blocks (weak scaling: every
-rank answers its own ``--rows`` query rows against the replicated reference set).
+and, with N > 1, the RCCL all-gather of the per-rank (dist, idx) blocks.
 
-Rank 0 prints ONE JSON line: BASELINE.json's metric (Mqueries/s, whole job), plus
-``roofline`` (dominant kernel = the MFMA pre-filter, timed with HIP events on its launch
-stream inside the library) and ``cpu_baseline`` (the reference's CPU arithmetic -- sklearn's
-ArgKmin + the restated reorder -- timed on this host on a bounded sample; N=1 only).
+N = 1 is BASELINE.json's headline shape (10M x 50k x 32, k = 5).  N > 1 defaults to STRONG
+scaling -- the same 10M-row job split over the ranks (`--scaling weak`: 10M rows per rank) --
+because BASELINE.json's configurations shard a fixed job over the GPUs of a node.
+
+Rank 0 prints ONE JSON line: BASELINE.json's metric (Mqueries/s, whole job) with
+  ``roofline``      dominant kernel = the MFMA pre-filter, HIP events on its launch stream inside
+                    the library, summed over the timed region;
+  ``cpu_baseline``  the reference's CPU arithmetic (sklearn ArgKmin + restated reorder) on this host
+                    on a bounded sample (N = 1 only);
+and, at N = 1 unless ``--no-extras``, ``configs`` (BASELINE.json configs 2-5 at one GPU, each with an
+oracle-checked slice), ``host_to_host_Mq_s`` / ``stream_Mq_s`` / ``estimator_Mq_s`` (the same
+workload entered from numpy arrays: PCIe-inclusive, never ``value``), ``cpu_baseline_c5`` (kd_tree
+and brute) and ``laws`` (reference/query laws that are hostile to the tile-level skip test).
 """
 
 from __future__ import annotations
@@ -41,64 +49,185 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="query rows per GPU")
+    ap.add_argument("--rows", type=int, default=10_000_000,
+                    help="query rows of the job (strong scaling: in total; weak: per GPU)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--refs", type=int, default=50_000)
     ap.add_argument("--dims", type=int, default=32)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--targets", type=int, default=40)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="rows of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (skip configs 2-5, host paths, laws)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (dist, idx)")
-    ap.add_argument("--predict", action="store_true", help="also time predict (distance weights) as an extra")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (self-test of the N>1 path)")
     return ap.parse_args()
 
 
-def make_queries(rows, dims, rank, torch):
-    """Synthetic law of SURVEY.md 8(d), generated on the device: Z @ (I + 0.3 G)."""
+def gen_queries(rows, dims, seed, torch, law="baseline"):
+    """Synthetic query rows generated on the device.  'baseline': SURVEY.md 8(d), Z @ (I + 0.3 G)."""
     from sknnr_amd import synth
 
-    g = torch.Generator(device="cuda").manual_seed(1000 + rank)
-    mix = torch.tensor(synth.mixing_matrix(dims), device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(seed)
     out = torch.empty((rows, dims), dtype=torch.float64, device="cuda")
     step = 1 << 21
+    mix = torch.tensor(synth.mixing_matrix(dims), device="cuda") if law == "baseline" else None
     for a in range(0, rows, step):
         b = min(rows, a + step)
-        out[a:b] = torch.randn((b - a, dims), dtype=torch.float64, device="cuda", generator=g) @ mix
+        if law == "baseline":
+            out[a:b] = torch.randn((b - a, dims), dtype=torch.float64, device="cuda", generator=g) @ mix
+        else:  # uniform hypercube
+            out[a:b] = torch.rand((b - a, dims), dtype=torch.float64, device="cuda", generator=g)
     return out
 
 
-def cpu_baseline(x_ref_t, center, proj, q_raw_sample, k):
-    """The reference's CPU path on this host: numpy transform + sklearn ArgKmin (what
+def fit_space(kind, n_ref, d_in, t, device, n_components=None, x_ref=None):
+    """Fit the feature space of one estimator family on synthetic references and build the engine:
+    returns (engine, x_ref_t, (center, scale, proj), y, fit_seconds)."""
+    from sknnr_amd import synth
+    from sknnr_amd import transformers as T
+    from sknnr_amd._engine import KNNEngine
+    from sknnr_amd._native import affine_transform_host
+
+    t0 = time.perf_counter()
+    if x_ref is None:
+        x_ref = synth.make_features(n_ref, d_in, seed=0)
+    y = synth.make_targets(x_ref, t=t, kind="positive" if kind == "gnn" else "linear")
+    if kind == "gnn":
+        tr = T.CCATransformer(n_components).fit(x_ref, y)
+    elif kind == "msn":
+        tr = T.CCorATransformer(n_components).fit(x_ref, y)
+    elif kind == "mahalanobis":
+        tr = T.MahalanobisTransformer().fit(x_ref)
+    elif kind == "euclidean":
+        tr = T.StandardScalerWithDOF(ddof=1).fit(x_ref)
+    else:
+        raise ValueError(kind)
+    center, scale, proj = tr.affine_params()
+    x_ref_t = affine_transform_host(x_ref, center, scale, proj, device=device)
+    eng = KNNEngine(x_ref_t, y, device=device)
+    eng.set_affine(d_in, center, scale, proj)
+    return eng, x_ref_t, (center, scale, proj), y, time.perf_counter() - t0
+
+
+def timed(fn, torch, steps=2, warmup=1):
+    for _ in range(warmup):
+        out = fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def oracle_slice_check(x_ref_t, affine, q_raw_slice, k, dist, idx, formula="expanded", pred=None, y=None, weights=None):
+    """Rows [0, n) of a run against the oracle on the same inputs."""
+    from oracle import oracle as O
+
+    c, s, p = affine
+    q_t = O.affine(q_raw_slice, c, s, p)
+    od, oi = O.kneighbors(x_ref_t, q_t, k, formula)
+    res = {"rows": int(len(q_raw_slice)), "index_rows_equal": int((idx == oi).all(axis=1).sum()),
+           "dist_bit_equal": bool(np.array_equal(dist, od)) if dist is not None else None}
+    if pred is not None:
+        want = O.predict(y, od, oi, weights)
+        res["max_rel_pred_err"] = float((np.abs(pred - want) / np.maximum(np.abs(want), 1e-300)).max())
+    return res
+
+
+def cpu_reference(x_ref_t, affine, q_raw_sample, k, algorithm="auto"):
+    """The reference's CPU path on this host: numpy transform + sklearn kneighbors (what
     RawKNNRegressor.kneighbors calls, REF _base.py:162-164) + the restated reorder."""
     from oracle import oracle as O
 
+    center, scale, proj = affine
     info = {"unit": "Mqueries/s", "sample": f"{len(q_raw_sample)} query rows of the same workload (prefix of rank 0's batch)"}
     try:
         import sklearn
         from sklearn.neighbors import KNeighborsRegressor
         from threadpoolctl import threadpool_info
 
-        reg = KNeighborsRegressor(n_neighbors=k, algorithm="auto").fit(x_ref_t, np.zeros(len(x_ref_t)))
+        reg = KNeighborsRegressor(n_neighbors=k, algorithm=algorithm).fit(x_ref_t, np.zeros(len(x_ref_t)))
         t0 = time.perf_counter()
-        q_t = (q_raw_sample - center) @ proj
+        q_t = q_raw_sample
+        if center is not None:
+            q_t = q_t - center
+        if scale is not None:
+            q_t = q_t / scale
+        if proj is not None:
+            q_t = q_t @ proj
         dist, idx = reg.kneighbors(q_t)
         dist, idx = O.deterministic_reorder(dist, idx)
         dt = time.perf_counter() - t0
         threads = [p.get("num_threads") for p in threadpool_info() if p.get("user_api") == "openmp"]
-        info.update(value=len(q_raw_sample) / dt / 1e6, cores=int(max(threads) if threads else os.cpu_count()),
-                    kind="reference", engine=f"scikit-learn {sklearn.__version__} ArgKmin ({reg._fit_method}) + restated reorder",
+        single = reg._fit_method != "brute"  # sklearn's tree queries run on one thread unless n_jobs is set
+        info.update(value=len(q_raw_sample) / dt / 1e6, cores=1 if single else int(max(threads) if threads else os.cpu_count()),
+                    kind="reference", engine=f"scikit-learn {sklearn.__version__} algorithm={algorithm!r} -> {reg._fit_method} + restated reorder",
                     host_cpus=os.cpu_count(), seconds=dt)
         return info, (dist, idx)
-    except Exception as err:  # sklearn missing on the box: time the C restatement instead
+    except ImportError as err:  # sklearn missing on the box: time the C restatement instead
         t0 = time.perf_counter()
-        q_t = O.affine(q_raw_sample, center, None, proj)
+        q_t = O.affine(q_raw_sample, center, scale, proj)
         dist, idx = O.kneighbors(x_ref_t, q_t, k, "expanded")
         dt = time.perf_counter() - t0
         info.update(value=len(q_raw_sample) / dt / 1e6, cores=O.num_threads(), kind="port",
                     engine=f"oracle/knn_oracle.c (OpenMP); sklearn unavailable: {err}", host_cpus=os.cpu_count(), seconds=dt)
         return info, (dist, idx)
+
+
+def mfma_frac(nq, n_ref, d_t, coarse_ms):
+    tf = 2.0 * nq * n_ref * d_t / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
+    return tf, tf / PEAK_F16_MFMA_TFLOPS
+
+
+def extra_config(name, kind, nq, n_ref, d_in, k, torch, device, *, t=40, n_components=None, predict=None,
+                 dataframe_ids=False, law="baseline", x_ref=None, check_rows=2048):
+    """One BASELINE configuration on one GPU, device-resident input: wall and kernel time, roofline
+    fraction of its pre-filter, and a slice checked against the oracle."""
+    eng, x_ref_t, affine, y, fit_s = fit_space(kind, n_ref, d_in, t, device, n_components, x_ref=x_ref)
+    d_t = x_ref_t.shape[1]
+    formula = "direct" if d_t <= 15 else "expanded"  # what algorithm="auto" resolves to (SKL/neighbors/_base.py:620-648)
+    q = gen_queries(nq, d_in, 4242, torch, law)
+    ids_table = torch.arange(n_ref, device="cuda", dtype=torch.int64) + 100_000 if dataframe_ids else None
+
+    def run():
+        if predict:
+            return eng.predict(q, k, predict, apply_affine=True, formula=formula)
+        dist, idx = eng.kneighbors(q, k, apply_affine=True, formula=formula)
+        if dataframe_ids:  # REF _base.py:177-180 on the device
+            idx = eng.crosswalk(idx, np.arange(n_ref, dtype=np.int64) + 100_000)
+        return dist, idx
+
+    run()
+    torch.cuda.synchronize()
+    eng.reset_stats()
+    wall, out = timed(run, torch, steps=2, warmup=0)
+    st = eng.stats()
+    coarse_ms = st["total_coarse_ms"] / max(1, st["timed_calls"])
+    kernel_ms = st["total_kernel_ms"] / max(1, st["timed_calls"])
+    tf, frac = mfma_frac(nq, n_ref, d_t, coarse_ms)
+    n_chk = min(check_rows, nq)
+    q_host = q[:n_chk].cpu().numpy()
+    if predict:
+        dist_c, idx_c = eng.kneighbors(q[:n_chk].contiguous(), k, apply_affine=True, formula=formula)
+        chk = oracle_slice_check(x_ref_t, affine, q_host, k, dist_c.cpu().numpy(), idx_c.cpu().numpy(), formula,
+                                 pred=out[:n_chk].cpu().numpy(), y=y, weights=predict)
+    else:
+        idx_h = out[1][:n_chk].cpu().numpy()
+        if dataframe_ids:
+            idx_h = idx_h - 100_000
+        chk = oracle_slice_check(x_ref_t, affine, q_host, k, out[0][:n_chk].cpu().numpy(), idx_h, formula)
+    res = {"workload": name, "Mq_s": nq / wall / 1e6, "ms": wall * 1e3, "kernel_ms": kernel_ms, "prefilter_ms": coarse_ms,
+           "prefilter_TFLOPs": tf, "frac": frac, "d_t": int(d_t), "formula": formula,
+           "exact_fallbacks_per_pass": int(st["exact_fallbacks"] / max(1, st["timed_calls"])),
+           "fit_seconds": fit_s, "oracle_check": chk}
+    assert frac <= 1.0, res
+    eng.close()
+    del q
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -121,38 +250,29 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from sknnr_amd import synth
-    from sknnr_amd._engine import KNNEngine
-    from sknnr_amd._native import affine_transform_host
     from sknnr_amd.distributed import cyclic_slot
-    from sknnr_amd.transformers import CCATransformer
 
     # ---- fit (host, once): CCA ordination of the synthetic reference set -> affine map ------
-    t_fit = time.perf_counter()
-    x_ref = synth.make_features(args.refs, args.dims, seed=0)
-    y_ref = synth.make_targets(x_ref, t=args.targets, kind="positive")
-    tr = CCATransformer().fit(x_ref, y_ref)
-    center, _, proj = tr.affine_params()
+    eng, x_ref_t, affine, y_ref, t_fit = fit_space("gnn", args.refs, args.dims, args.targets, local_rank)
+    center, _, proj = affine
     d_t = proj.shape[1]
-    x_ref_t = affine_transform_host(x_ref, center, None, proj, device=local_rank)
-    eng = KNNEngine(x_ref_t, y_ref, device=local_rank)
-    eng.set_affine(args.dims, center, None, proj)
-    t_fit = time.perf_counter() - t_fit
 
-    q = make_queries(args.rows, args.dims, rank, torch)
-    nq, k = args.rows, args.k
-    stream = torch.cuda.current_stream()
+    # strong scaling: the job's rows are split over the ranks; weak: every rank gets --rows rows
+    nq = args.rows // world if args.scaling == "strong" else args.rows
+    total_rows = nq * world
+    k = args.k
+    q = gen_queries(nq, args.dims, 1000 + rank, torch)
 
     # N > 1: four all-gather chunks (chunk i travels while chunk i+1 is computed), cut at whole rounds
     # of the pre-filter grid (256 CUs x 1024 rows per workgroup) and shrinking, so that the last
     # gather -- the only one nothing hides -- is the smallest
     round_rows = 256 * 1024
-    n_rounds = -(-args.rows // round_rows)
+    n_rounds = -(-nq // round_rows)
     cuts, acc_w = [0], 0.0
     for w_ in (0.31, 0.28, 0.23):
         acc_w += w_
-        cuts.append(min(args.rows, max(cuts[-1], int(round(acc_w * n_rounds)) * round_rows)))
-    cuts.append(args.rows)
+        cuts.append(min(nq, max(cuts[-1], int(round(acc_w * n_rounds)) * round_rows)))
+    cuts.append(nq)
     gather_chunks = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
     comm_stream = torch.cuda.Stream() if use_dist else None
     gather_in_place = [True]
@@ -200,81 +320,74 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    coarse_ms = 0.0
-    kernel_ms = 0.0
+    eng.reset_stats()  # kernel timings below are summed over every call of the timed region
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         d_out, i_out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-kernel device time of the LAST step (HIP events recorded by the library on the launch stream)
     st = eng.stats()
-    coarse_ms, kernel_ms = st["last_coarse_ms"], st["last_kernel_ms"]
+    coarse_ms = st["total_coarse_ms"] / args.steps   # pre-filter kernel, per step (all chunks of the step)
+    kernel_ms = st["total_kernel_ms"] / args.steps
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * nq * args.steps / elapsed / 1e6
-
-    extra = {}
-    if args.predict:
-        for _ in range(max(1, args.warmup)):
-            p = eng.predict(q, 7, "distance", apply_affine=True)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            p = eng.predict(q, 7, "distance", apply_affine=True)
-        barrier()
-        extra["predict_k7_distance_Mq_s"] = nq * args.steps / (time.perf_counter() - t1) / 1e6
-        del p
+    value = total_rows * args.steps / elapsed / 1e6
 
     if rank == 0:
-        alg_flops = 2.0 * nq * args.refs * d_t  # 2 Nq Nref D_t per pass
-        achieved_tf = alg_flops / (coarse_ms * 1e-3) / 1e12
+        achieved_tf, frac = mfma_frac(nq, args.refs, d_t, coarse_ms)  # this rank's rows through this rank's kernel
         alg_bytes = nq * args.dims * 8 + args.refs * d_t * 8 + nq * k * 16
         traffic, traffic_note = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_coarse_pmc.json")
-        if os.path.exists(pmc_file) and (args.refs, d_t, k) == (50_000, 32, 5):
-            # PMC counters cannot be collected inside this process; the committed rocprofv3 --pmc
-            # passes of this same command give HBM bytes per query row for the dominant kernel
-            # (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section), scaled to this step.
-            pmc = json.load(open(pmc_file))
-            traffic = pmc["hbm_bytes_per_query_row"] * nq
-            traffic_note = "profiles/r01_coarse_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE), bytes per step"
+        for pmc_name in ("r02_coarse_pmc.json", "r01_coarse_pmc.json"):
+            pmc_file = os.path.join(ROOT, "profiles", pmc_name)
+            if os.path.exists(pmc_file) and (args.refs, d_t, k) == (50_000, 32, 5):
+                # PMC counters cannot be collected inside this process; the committed rocprofv3 --pmc
+                # passes of this same command give HBM bytes per query row for the dominant kernel
+                # (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section), scaled to this step.
+                pmc = json.load(open(pmc_file))
+                traffic = pmc["hbm_bytes_per_query_row"] * nq
+                traffic_note = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE), bytes per step"
+                break
+        assert frac <= 1.0, (frac, coarse_ms, st)
         roofline = {
-            "kernel": "sknnr::coarse_kernel<KS=%d,M=%d,NQB=2> (f16x3 split MFMA pre-filter, correction products skipped when no lane can hit; lane-local top-M)" % ((d_t + 15) // 16, 6 if k <= 5 else 8),
+            "kernel": "sknnr::coarse_kernel<KS=%d,M=%d> (f16x3 split MFMA pre-filter, correction products skipped when no lane can hit; lane-local top-M)" % ((d_t + 15) // 16, 6 if k <= 5 else 8),
             "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved_tf / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+            "frac": frac, "traffic": traffic, "traffic_note": traffic_note,
             "executed_over_algorithmic_max": 3.0,
             "vs_f32_mfma_peak": achieved_tf / PEAK_F32_MFMA_TFLOPS,
             "kernel_ms_per_step": coarse_ms, "all_kernels_ms_per_step": kernel_ms,
+            "timed_calls": int(st["timed_calls"]),
             "hbm_algorithmic_GBs": alg_bytes / (kernel_ms * 1e-3) / 1e9,
             "hbm_frac_of_peak": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
         }
         result = {
             "metric": "Mqueries/sec + achieved HBM GB/s, 10M x 50k x 32 k=5, 1/2/4/8 MI355X",
             "value": value, "unit": "Mqueries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f16x3 split MFMA (f32 accumulate) pre-filter + f64 exact re-score",
             "data": "synthetic",
             "config": {
                 "workload": f"GNN-style kneighbors: affine {args.dims}->{d_t} (CCA fit on synthetic refs) + "
-                            f"{nq} query rows/GPU x {args.refs} refs x {d_t} dims, k={k}, deterministic reorder, "
-                            "float64 (dist, idx) out" + (" + RCCL all-gather" if use_dist and not args.no_gather else ""),
-                "rows_per_gpu": nq, "n_ref": args.refs, "d_in": args.dims, "d_t": int(d_t), "k": k,
+                            f"{total_rows} query rows in total ({nq} per GPU, {args.scaling} scaling) x {args.refs} refs x "
+                            f"{d_t} dims, k={k}, deterministic reorder, float64 (dist, idx) out"
+                            + (" + RCCL all-gather" if use_dist and not args.no_gather else ""),
+                "total_rows": total_rows, "rows_per_gpu": nq, "n_ref": args.refs, "d_in": args.dims, "d_t": int(d_t), "k": k,
                 "parallelism": f"query-row shards x{world}",
             },
             "roofline": roofline,
             "fit_seconds": t_fit,
-            "exact_fallbacks": int(st["exact_fallbacks"]), "queries_answered": int(st["queries"]),
-            **extra,
+            "exact_fallbacks_per_step": int(st["exact_fallbacks"] / args.steps), "queries_answered": int(st["queries"]),
         }
+        if use_dist:
+            result["gather_in_place"] = gather_in_place[0]
         if world == 1 and not args.no_cpu_baseline:
             n_s = min(args.cpu_sample, nq)
             q_host = q[:n_s].cpu().numpy()
-            base, (cd, ci) = cpu_baseline(x_ref_t, center, proj, q_host, k)
+            base, (cd, ci) = cpu_reference(x_ref_t, affine, q_host, k)
             result["cpu_baseline"] = base
             gi = i_out[rank * nq: rank * nq + n_s].cpu().numpy() if use_dist and not args.no_gather else i_out[:n_s].cpu().numpy()
             gd = d_out[rank * nq: rank * nq + n_s].cpu().numpy() if use_dist and not args.no_gather else d_out[:n_s].cpu().numpy()
@@ -284,9 +397,91 @@ def main():
                 "max_rel_dist_err": float(rel.max()),
             }
             result["speedup_vs_cpu"] = value / base["value"]
+        if world == 1 and not args.no_extras and not use_dist:
+            del d_out, i_out
+            result.update(extras(args, eng, q, x_ref_t, affine, torch, local_rank))
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+
+
+def extras(args, eng, q, x_ref_t, affine, torch, device):
+    """Everything BASELINE.json / SURVEY.md 8(d) ask for beyond the headline line, at one GPU."""
+    out = {}
+    nq, k = q.shape[0], args.k
+
+    # ---- the headline workload entered from host arrays (PCIe-inclusive; never `value`) ----------
+    q_host = q.cpu().numpy()
+    wall, (hd, hi) = timed(lambda: eng.kneighbors(q_host, k, apply_affine=True), torch, steps=1, warmup=1)
+    out["host_to_host_Mq_s"] = nq / wall / 1e6
+    tile = 1_000_000
+    d_st = np.empty((nq, k))
+    i_st = np.empty((nq, k), dtype=np.int64)
+
+    def stream_run():
+        with eng.open_stream(k, apply_affine=True) as s:
+            for a in range(0, nq, tile):
+                s.push(q_host[a:a + tile], out_idx=i_st[a:a + tile], out_dist=d_st[a:a + tile])
+        return None
+
+    wall, _ = timed(stream_run, torch, steps=1, warmup=0)
+    out["stream_Mq_s"] = nq / wall / 1e6
+    out["stream_note"] = (f"{-(-nq // tile)} pushes of {tile} rows through sknnr_stream_*; equals the one-call result: "
+                          f"{bool(np.array_equal(i_st, hi) and np.array_equal(d_st, hd))}")
+    del d_st, i_st, hd, hi
+
+    # ---- the same workload through the estimator surface (GNNRegressor.kneighbors(X_numpy)) -----
+    import sknnr_amd
+    from sknnr_amd import synth
+
+    x_ref = synth.make_features(args.refs, args.dims, seed=0)
+    y = synth.make_targets(x_ref, t=args.targets, kind="positive")
+    t0 = time.perf_counter()
+    est = sknnr_amd.GNNRegressor(n_neighbors=k).fit(x_ref, y)
+    est_fit = time.perf_counter() - t0
+    wall, _ = timed(lambda: est.kneighbors(q_host), torch, steps=1, warmup=1)
+    out["estimator_Mq_s"] = nq / wall / 1e6
+    out["estimator_note"] = (f"GNNRegressor(n_neighbors={k}).fit in {est_fit:.2f} s (incl. independent prediction), "
+                             "kneighbors(X_numpy) wall: sklearn validate_data (no host finiteness pass) + host pipeline")
+    del est, q_host
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE.json configs 2-5 on one GPU --------------------------------------------------------
+    cfgs = []
+    cfgs.append(extra_config("C2 EuclideanKNNRegressor 1M x 10k x 16, k=5", "euclidean", 1_000_000, 10_000, 16, 5, torch, device))
+    cfgs.append(extra_config("C3 GNNRegressor 10M x 50k x 32, k=7, predict weights='distance', T=40", "gnn",
+                             10_000_000, 50_000, 32, 7, torch, device, predict="distance"))
+    cfgs.append(extra_config("C4 MahalanobisKNNRegressor 10M x 50k x 64, k=5 (whole job on one GPU)", "mahalanobis",
+                             10_000_000, 50_000, 64, 5, torch, device))
+    cfgs.append(extra_config("C5 MSNRegressor(n_components=8) 6.25M (one GPU's share of 50M) x 100k x 32->8, k=1, dataframe ids",
+                             "msn", 6_250_000, 100_000, 32, 1, torch, device, n_components=8, dataframe_ids=True))
+    out["configs"] = cfgs
+
+    # ---- C5's CPU baseline: sklearn picks a single-threaded kd_tree for D_t <= 15; report brute too ----
+    try:
+        eng5, x5_t, aff5, _, _ = fit_space("msn", 100_000, 32, args.targets, device, 8)
+        q5 = gen_queries(100_000, 32, 4242, torch).cpu().numpy()
+        c5 = {}
+        for alg in ("auto", "brute"):
+            info, _ = cpu_reference(x5_t, aff5, q5, 1, algorithm=alg)
+            c5[alg] = info
+        out["cpu_baseline_c5"] = c5
+        eng5.close()
+    except Exception as err:  # a missing sklearn must not cost the whole line
+        out["cpu_baseline_c5"] = {"error": repr(err)}
+
+    # ---- laws hostile to the tile-level skip test (data-dependence of `value`) ---------------------
+    laws = []
+    rng = np.random.default_rng(0)
+    cube = rng.random((args.refs, args.dims))
+    laws.append(extra_config("uniform hypercube refs and queries, 10M x 50k x 32, k=5 (Euclidean space)", "euclidean",
+                             10_000_000, args.refs, args.dims, 5, torch, device, law="uniform", x_ref=cube))
+    srt = synth.make_features(args.refs, args.dims, seed=0)
+    srt = np.ascontiguousarray(srt[np.argsort(srt[:, 0])])
+    laws.append(extra_config("baseline law, reference rows sorted by feature 0, 10M x 50k x 32, k=5 (GNN space)", "gnn",
+                             10_000_000, args.refs, args.dims, 5, torch, device, x_ref=srt))
+    out["laws"] = laws
+    return out
 
 
 if __name__ == "__main__":

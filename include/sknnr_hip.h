@@ -17,7 +17,9 @@
  * the calling thread's last failure.  All matrices are row-major (C order) float64,
  * indices are int64 -- exactly what the reference hands to / gets from scikit-learn.
  * The caller owns every buffer it passes; the handle owns its device copies.
- * One call at a time per handle.
+ * One call at a time per handle: entry points serialise on a per-handle mutex, and a call that is handed a
+ * different stream than the previous one first makes that stream wait (hipStreamWaitEvent) for the previous
+ * call's last kernel, because both use the handle's workspace.
  */
 #ifndef SKNNR_HIP_H
 #define SKNNR_HIP_H
@@ -30,7 +32,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden; exactly these declarations are exported. */
 #pragma GCC visibility push(default)
 
-#define SKNNR_ABI_VERSION 1
+#define SKNNR_ABI_VERSION 2
 
 typedef enum sknnr_status {
     SKNNR_OK = 0,
@@ -39,7 +41,11 @@ typedef enum sknnr_status {
     SKNNR_ERR_NO_TARGETS = -3,  /* predict without targets */
     SKNNR_ERR_UNSUPPORTED = -4, /* outside the envelope of the HIP kernels (no CPU fallback exists) */
     SKNNR_ERR_HIP = -5,         /* HIP runtime failure (message carries hipGetErrorString) */
-    SKNNR_ERR_NO_DEVICE = -6    /* no usable gfx950 device */
+    SKNNR_ERR_NO_DEVICE = -6,   /* no usable gfx950 device */
+    SKNNR_ERR_NONFINITE = -7    /* query rows contain NaN or infinity; the message is scikit-learn's
+                                   ("Input X contains NaN." / "Input X contains infinity or a value too large
+                                   for dtype('float64')."): SKL/utils/validation.py _assert_all_finite, reached
+                                   from SKL/neighbors/_base.py:838-845 and REF transformers' transform() */
 } sknnr_status;
 
 /* Where the caller's query/output buffers live. */
@@ -77,7 +83,10 @@ typedef struct sknnr_query_opts {
     int32_t apply_affine;  /* 1 = queries are untransformed (d_in columns) and the handle's affine map
                               is applied first (REF _base.py:236-239); 0 = already transformed (d columns) */
     int32_t weight_mode;   /* predict only: sknnr_weight_mode */
-    int32_t reserved;
+    int32_t check_finite;  /* 1 = the kernels that read the query rows also test them for NaN / infinity
+                              (what validate_data(ensure_all_finite=True) does on the host in the reference).
+                              Host-memory calls then fail with SKNNR_ERR_NONFINITE; device-memory calls stay
+                              asynchronous and the caller polls sknnr_check_finite() */
     int64_t row_offset;    /* position of query row 0 inside the logical call: key 2 of the reorder is
                               |idx - row| with row counted over the whole call (REF _base.py:171), so a
                               shard or chunk must carry its global offset */
@@ -91,6 +100,9 @@ typedef struct sknnr_stats {
     int64_t exact_only_queries;/* rows answered by the float64 scan alone (k or d outside the MFMA envelope) */
     double  last_kernel_ms;    /* device time of the most recent call (hipEvent, launch stream) */
     double  last_coarse_ms;    /* ... of which the MFMA pre-filter kernel */
+    double  total_kernel_ms;   /* device time of all calls since the last reset (sums the chunks of a step) */
+    double  total_coarse_ms;   /* ... of which the MFMA pre-filter kernel */
+    int64_t timed_calls;       /* calls summed in the two totals */
 } sknnr_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */
@@ -145,6 +157,15 @@ int sknnr_index_shape(const sknnr_index* index, int64_t* n_ref, int32_t* d, int3
 int sknnr_get_stats(const sknnr_index* index, sknnr_stats* out);
 int sknnr_reset_stats(sknnr_index* index);
 
+/*
+ * Poll (and clear) the non-finite-input flag raised by calls made with opts->check_finite = 1 on device
+ * memory.  Synchronises `stream` (the stream those calls ran on).  Returns SKNNR_OK or
+ * SKNNR_ERR_NONFINITE with scikit-learn's message.  Replaces the finiteness half of
+ * validate_data(..., ensure_all_finite=True) (REF transformers/_cca_transformer.py:78-86,
+ * SKL/neighbors/_base.py:838-845) for rows that never visit the host.
+ */
+int sknnr_check_finite(sknnr_index* index, void* stream);
+
 /* ---- the hot path ---------------------------------------------------------------------- */
 
 /*
@@ -181,6 +202,37 @@ int sknnr_predict(sknnr_index* index, const double* q, int64_t nq, const sknnr_q
 int sknnr_predict_from_neighbors(sknnr_index* index, const double* dist, const int64_t* idx,
                                  const double* w, int64_t nq, int32_t k, int32_t weight_mode,
                                  double* out_pred, int32_t mem, void* stream);
+
+/* ---- streamed query tiles (raster ingestion) ------------------------------------------------ */
+
+/*
+ * Wall-to-wall mapping feeds the hot path tile by tile: the reference's documented workflow predicts
+ * plot IDs / attributes for every pixel of a raster (REF docs/pages/usage.md:101-128, README.md:66-67),
+ * i.e. calls kneighbors(X_tile, return_dataframe_index=True) / predict(X_tile) once per block of pixels.
+ * A stream keeps the handle's three-stream PCIe pipeline (copy-in | kernels | copy-out) full ACROSS
+ * those calls and carries the global row offset itself, so that N pushes give bit for bit what one call
+ * on the concatenated rows gives (key 2 of the reorder, REF _base.py:171, counts rows over the whole
+ * logical call).
+ *
+ *   begin : opts as for sknnr_kneighbors / sknnr_predict (exclude_self must be 0); opts->row_offset is
+ *           the global row of the first pushed row.  want_dist / want_pred say which optional outputs
+ *           later pushes may ask for.  One open stream per handle; host-memory kneighbors/predict
+ *           calls on the handle fail while it is open (device-memory calls are allowed).
+ *   push  : q is a HOST (nq, d_in or d) tile and may be reused as soon as the call returns.  The
+ *           tile's results are written to the HOST buffers passed with it -- out_idx (nq, k), out_dist
+ *           (nq, k) or NULL, out_pred (nq, t) or NULL -- at the latest when the second-next push, a
+ *           flush or end returns; the buffers must stay valid until then.
+ *   flush : every pushed tile's results are in place on return.  With opts->check_finite the status
+ *           is SKNNR_ERR_NONFINITE if any pushed value was NaN or infinite.
+ *   end   : flush, then free the stream (NULL is allowed); *rows_pushed (optional) = total rows.
+ */
+typedef struct sknnr_stream sknnr_stream;
+int sknnr_stream_begin(sknnr_index* index, const sknnr_query_opts* opts, int32_t want_dist, int32_t want_pred,
+                       sknnr_stream** out);
+int sknnr_stream_push(sknnr_stream* stream, const double* q, int64_t nq, double* out_dist, int64_t* out_idx,
+                      double* out_pred);
+int sknnr_stream_flush(sknnr_stream* stream);
+int sknnr_stream_end(sknnr_stream* stream, int64_t* rows_pushed);
 
 /*
  * Dataframe-index crosswalk: out[i] = table[idx[i]].

@@ -31,7 +31,7 @@ while time.time() < t_end:
         d = int(rng.choice([8, 16, 32, 64]))
     kmax = min(n_ref, 34)
     k = int(rng.integers(1, kmax + 1))
-    kind = rng.choice(["smooth", "dup", "integer", "tiny_scale", "huge_offset"])
+    kind = rng.choice(["smooth", "dup", "integer", "tiny_scale", "huge_offset", "huge_offset", "far_queries"])
     x_ref, _, x_q = synth.make_problem(max(n_ref, 2), nq, d, t=1, n_dup_refs=min(n_ref // 3, 40) if kind == "dup" else 0,
                                        n_dup_queries=min(nq // 3, 30, max(n_ref, 2) // 2) if kind == "dup" else 0)
     x_ref = x_ref[:n_ref]
@@ -41,7 +41,12 @@ while time.time() < t_end:
     elif kind == "tiny_scale":
         x_ref, x_q = x_ref * 1e-5, x_q * 1e-5
     elif kind == "huge_offset":
-        x_ref, x_q = x_ref + 1e4, x_q + 1e4
+        # uncentred data: at 1e6 and beyond the reference formula's cancellation noise decides near ties
+        off = float(rng.choice([1e4, 1e5, 1e6, 1e7, 1e9]))
+        x_ref, x_q = x_ref + off, x_q + off
+    elif kind == "far_queries":
+        # some query values beyond the f16 image of the pre-filter (marked rows, exact scan)
+        x_q = x_q * np.where(rng.random((nq, 1)) < 0.2, 1e7, 1.0)
     x_ref_raw = x_ref
     formula = int(rng.integers(0, 2))
     fname = "expanded" if formula == 0 else "direct"

@@ -63,6 +63,21 @@ def _resolve_fit_method(algorithm, n_ref, d, k):
     return "kd_tree"
 
 
+def _reraise(err, estimator):
+    """Map a native failure to the exception the reference raises for the same input."""
+    if err.code == _native.ERR_K_TOO_LARGE:
+        raise ValueError(err.message) from None
+    if err.code == _native.ERR_NONFINITE:
+        # scikit-learn's own wording, estimator-specific second sentence included
+        # (SKL/utils/validation.py _assert_all_finite)
+        from sklearn.utils.validation import check_array
+
+        bad = np.array([[np.nan if "NaN" in err.message else np.inf]])
+        check_array(bad, estimator=estimator, input_name="X", ensure_min_features=1)
+        raise ValueError(err.message) from None  # not reached
+    raise err
+
+
 class DFIndexCrosswalkMixin:
     """Capture of a dataframe's index at fit time (REF _base.py:23-30)."""
 
@@ -165,7 +180,9 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
                     f"X has {X.shape[1] if X.ndim == 2 else '?'} features, but {type(self).__name__} "
                     f"is expecting {self.n_features_in_} features as input.")
             return X
-        return validate_data(self, X, reset=False, order="C", dtype=np.float64, ensure_all_finite=True)
+        # feature count / names / dtype here; finiteness is tested by the kernels that read the rows
+        # (check_finite), not by a second pass over them on the host
+        return validate_data(self, X, reset=False, order="C", dtype=np.float64, ensure_all_finite=False)
 
     def _resolve_k(self, n_neighbors):
         if n_neighbors is None:
@@ -178,17 +195,15 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
         return int(n_neighbors)
 
     def _kneighbors_engine(self, X, k, *, apply_affine, use_deterministic_ordering, row_offset=0,
-                           n_self_rows=None, return_distance=True, out=None):
+                           n_self_rows=None, return_distance=True, out=None, owner=None):
         try:
             return self.engine_.kneighbors(
                 X, k, exclude_self=X is None, deterministic=use_deterministic_ordering,
                 decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
                 apply_affine=apply_affine, row_offset=row_offset, n_self_rows=n_self_rows,
-                return_distance=return_distance, out=out)
+                return_distance=return_distance, out=out, check_finite=X is not None)
         except _native.HipBackendError as err:
-            if err.code == _native.ERR_K_TOO_LARGE:
-                raise ValueError(err.message) from None
-            raise
+            _reraise(err, owner if owner is not None else self)
 
     def kneighbors(self, X=None, n_neighbors=None, return_distance=True, return_dataframe_index=False,
                    use_deterministic_ordering=True):
@@ -216,12 +231,16 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
                 idx = table[host_idx]
         return (dist, idx) if return_distance else idx
 
-    def _predict_engine(self, X, *, apply_affine, row_offset=0, n_self_rows=None):
+    def _predict_engine(self, X, *, apply_affine, row_offset=0, n_self_rows=None, owner=None):
         weights = None if self.weights is None else self.weights
-        pred = self.engine_.predict(
-            X, self.n_neighbors, "uniform" if weights is None else weights, exclude_self=X is None,
-            deterministic=True, decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
-            apply_affine=apply_affine, row_offset=row_offset, n_self_rows=n_self_rows)
+        try:
+            pred = self.engine_.predict(
+                X, self.n_neighbors, "uniform" if weights is None else weights, exclude_self=X is None,
+                deterministic=True, decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
+                apply_affine=apply_affine, row_offset=row_offset, n_self_rows=n_self_rows,
+                check_finite=X is not None)
+        except _native.HipBackendError as err:
+            _reraise(err, owner if owner is not None else self)
         if self._y.ndim == 1:
             pred = pred.reshape(-1)
         return pred
@@ -232,12 +251,108 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
         check_is_fitted(self, "_fit_X")
         if X is not None:
             X = self._validate_query(X)
+        return self._predict_engine(X, apply_affine=False)
+
+    # -- streamed tiles (raster ingestion; REF docs/pages/usage.md:101-128) --------------------
+    def _stream_tiles(self, tiles, validate, k, *, apply_affine, weights, return_distance,
+                      use_deterministic_ordering, out, owner):
+        """Push host tiles through one native query stream.  Returns (dist, idx, pred) arrays over all
+        pushed rows (pieces of ``out`` when given, else concatenated)."""
+        eng = self.engine_
+        want_pred = weights is not None
+        t_cols = eng.t
+        o_dist, o_idx, o_pred = out if out is not None else (None, None, None)
+        pieces = []
+        row = 0
         try:
-            return self._predict_engine(X, apply_affine=False)
+            with eng.open_stream(k, weights=weights, want_dist=return_distance,
+                                 deterministic=use_deterministic_ordering,
+                                 decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
+                                 apply_affine=apply_affine, check_finite=True) as stream:
+                for tile in tiles:
+                    if is_torch_cuda_tensor(tile):
+                        raise TypeError("streamed tiles are host arrays (they travel through the pinned "
+                                        "PCIe pipeline); pass CUDA tensors to kneighbors() / predict()")
+                    tile = validate(tile)
+                    n = tile.shape[0]
+                    if n == 0:
+                        continue
+
+                    def window(arr, cols, dtype):
+                        if arr is None:
+                            return None
+                        w = arr[row:row + n]
+                        if w.shape != (n, cols) or w.dtype != dtype or not w.flags.c_contiguous:
+                            raise ValueError(f"out arrays must be C-contiguous, {np.dtype(dtype)}, with "
+                                             f"{cols} columns and at least {row + n} rows")
+                        return w
+
+                    got = stream.push(tile, out_idx=window(o_idx, k, np.int64),
+                                      out_dist=window(o_dist, k, np.float64) if return_distance else None,
+                                      out_pred=window(o_pred, t_cols, np.float64) if want_pred else None,
+                                      need_idx=not want_pred)
+                    if out is None:
+                        pieces.append(got)
+                    row += n
         except _native.HipBackendError as err:
-            if err.code == _native.ERR_K_TOO_LARGE:
-                raise ValueError(err.message) from None
-            raise
+            _reraise(err, owner if owner is not None else self)
+        if out is not None:
+            trim = lambda a: None if a is None else a[:row]  # noqa: E731
+            return trim(o_dist) if return_distance else None, trim(o_idx), trim(o_pred) if want_pred else None
+        cat = lambda i, cols, dt: (np.concatenate([p[i] for p in pieces]) if pieces  # noqa: E731
+                                   else np.empty((0, cols), dtype=dt))
+        return (cat(1, k, np.float64) if return_distance else None,
+                None if want_pred else cat(0, k, np.int64),
+                cat(2, t_cols, np.float64) if want_pred else None)
+
+    def kneighbors_chunks(self, tiles, n_neighbors=None, return_distance=True, return_dataframe_index=False,
+                          use_deterministic_ordering=True, out=None):
+        """``kneighbors`` over an iterable of host tiles ``(n_i, n_features)`` -- windows of a raster,
+        slices of a ``numpy.memmap`` -- as ONE logical call: the copy-in / kernels / copy-out pipeline
+        stays full across tiles and row positions count over all tiles, so the result equals
+        ``kneighbors(np.concatenate(tiles))`` bit for bit.  ``out=(dist, idx)`` (``dist`` may be None):
+        preallocated arrays (e.g. memmaps) that receive the rows in order."""
+        check_is_fitted(self, "_fit_X")
+        k = self._resolve_k(n_neighbors)
+        o = None if out is None else (out[0], out[1], None)
+        dist, idx, _ = self._stream_tiles(tiles, self._validate_query, k, apply_affine=False, weights=None,
+                                          return_distance=return_distance,
+                                          use_deterministic_ordering=use_deterministic_ordering, out=o, owner=None)
+        return self._finish_chunks(dist, idx, return_distance, return_dataframe_index)
+
+    def _finish_chunks(self, dist, idx, return_distance, return_dataframe_index):
+        if return_dataframe_index:
+            msg = "Dataframe indexes can only be returned when fitted with a dataframe."
+            check_is_fitted(self, "dataframe_index_in_", msg=msg)
+            table = self.dataframe_index_in_
+            if table.dtype == np.int64:
+                step = 1 << 22  # in place, block by block: idx may be a memmap larger than memory
+                for a in range(0, idx.shape[0], step):
+                    idx[a:a + step] = table[idx[a:a + step]]
+            else:
+                idx = table[idx]
+        return (dist, idx) if return_distance else idx
+
+    def predict_chunks(self, tiles, out=None):
+        """``predict`` over an iterable of host tiles as one streamed call; ``out``: preallocated
+        ``(n_rows, n_targets)`` float64 array (e.g. a memmap)."""
+        check_is_fitted(self, "_fit_X")
+        return self._predict_chunks(tiles, self._validate_query, apply_affine=False, out=out, owner=None)
+
+    def _predict_chunks(self, tiles, validate, *, apply_affine, out, owner):
+        weights = "uniform" if self.weights is None else self.weights
+        if callable(weights):  # a Python callable runs between the search and the reduction: tile by tile
+            preds = [self._predict_engine(validate(t), apply_affine=apply_affine, owner=owner) for t in tiles]
+            pred = np.concatenate([p.reshape(len(p), -1) for p in preds]) if preds else np.empty((0, self.engine_.t))
+            if out is not None:
+                out[:len(pred)] = pred
+                pred = out[:len(pred)]
+        else:
+            o = None if out is None else (None, None, out.reshape(out.shape[0], -1))
+            _, _, pred = self._stream_tiles(tiles, validate, self.n_neighbors, apply_affine=apply_affine,
+                                            weights=weights, return_distance=False,
+                                            use_deterministic_ordering=True, out=o, owner=owner)
+        return pred.reshape(-1) if self._y.ndim == 1 else pred
 
     def score(self, X, y, sample_weight=None):
         """R^2 of ``predict(X)`` (``X`` may be None as in REF _base.py:40)."""
@@ -325,8 +440,9 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
                 raise ValueError(f"X has {X.shape[-1]} features, but {type(self).__name__} is expecting "
                                  f"{d_in} features as input.")
             return X
+        # finiteness is tested on the device by the kernel that reads the rows (check_finite)
         return validate_data(self.transformer_, X=X, reset=False, dtype=np.float64, order="C",
-                             ensure_all_finite=True)
+                             ensure_all_finite=False)
 
     def kneighbors(self, X=None, n_neighbors=None, return_distance=True, return_dataframe_index=False,
                    use_deterministic_ordering=True):
@@ -337,19 +453,37 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
         if X is not None:
             X = self._validate_raw_query(X)
         dist, idx = reg._kneighbors_engine(X, k, apply_affine=X is not None,
-                                           use_deterministic_ordering=use_deterministic_ordering)
+                                           use_deterministic_ordering=use_deterministic_ordering,
+                                           owner=self.transformer_)
         return reg._finish_kneighbors(dist, idx, return_distance, return_dataframe_index)
 
     def predict(self, X):
-        """REF _base.py:346-348."""
+        """REF _base.py:346-348 (``X=None``: the independent prediction, as the reference's
+        ``_transform_X(None)`` passes None through to the regressor)."""
         check_is_fitted(self, "regressor_")
-        X = self._validate_raw_query(X)
-        try:
-            return self.regressor_._predict_engine(X, apply_affine=True)
-        except _native.HipBackendError as err:
-            if err.code == _native.ERR_K_TOO_LARGE:
-                raise ValueError(err.message) from None
-            raise
+        if X is not None:
+            X = self._validate_raw_query(X)
+        return self.regressor_._predict_engine(X, apply_affine=X is not None, owner=self.transformer_)
+
+    def kneighbors_chunks(self, tiles, n_neighbors=None, return_distance=True, return_dataframe_index=False,
+                          use_deterministic_ordering=True, out=None):
+        """``kneighbors`` over an iterable of untransformed host tiles as one streamed call (see
+        :meth:`RawKNNRegressor.kneighbors_chunks`); each tile is transformed on the device."""
+        check_is_fitted(self, "regressor_")
+        reg = self.regressor_
+        k = reg._resolve_k(n_neighbors)
+        o = None if out is None else (out[0], out[1], None)
+        dist, idx, _ = reg._stream_tiles(tiles, self._validate_raw_query, k, apply_affine=True, weights=None,
+                                         return_distance=return_distance,
+                                         use_deterministic_ordering=use_deterministic_ordering, out=o,
+                                         owner=self.transformer_)
+        return reg._finish_chunks(dist, idx, return_distance, return_dataframe_index)
+
+    def predict_chunks(self, tiles, out=None):
+        """``predict`` over an iterable of untransformed host tiles as one streamed call."""
+        check_is_fitted(self, "regressor_")
+        return self.regressor_._predict_chunks(tiles, self._validate_raw_query, apply_affine=True, out=out,
+                                               owner=self.transformer_)
 
     def score(self, X, y):
         """REF _base.py:350-352."""

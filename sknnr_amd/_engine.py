@@ -83,11 +83,23 @@ class KNNEngine:
 
     # ------------------------------------------------------------------------------------
     def _opts(self, k, *, exclude_self, deterministic, decimals, formula, apply_affine,
-              weight_mode=_native.WEIGHTS_UNIFORM, row_offset=0):
+              weight_mode=_native.WEIGHTS_UNIFORM, row_offset=0, check_finite=False):
         return self._index.make_opts(
             k, exclude_self=exclude_self, deterministic=deterministic, decimals=decimals,
             formula=_native.FORMULA_DIRECT if formula == "direct" else _native.FORMULA_EXPANDED,
-            apply_affine=apply_affine, weight_mode=weight_mode, row_offset=row_offset)
+            apply_affine=apply_affine, weight_mode=weight_mode, row_offset=row_offset,
+            check_finite=check_finite)
+
+    def _as_device_rows(self, X, apply_affine):
+        """A float64, contiguous CUDA tensor on the engine's device with the expected columns."""
+        import torch
+
+        if X.dtype != torch.float64 or not X.is_contiguous():
+            X = X.to(torch.float64).contiguous()
+        if X.device.index != self.device:
+            raise ValueError(f"X is on cuda:{X.device.index}, the engine on cuda:{self.device}")
+        self._check_columns(X, apply_affine)
+        return X
 
     def _check_columns(self, X, apply_affine):
         want = self.d_in if apply_affine else self.d
@@ -96,14 +108,17 @@ class KNNEngine:
 
     def kneighbors(self, X, k, *, exclude_self=False, deterministic=True, decimals=10,
                    formula="expanded", apply_affine=False, row_offset=0, n_self_rows=None,
-                   return_distance=True, out=None):
+                   return_distance=True, out=None, check_finite=False):
         """Neighbours of the rows of ``X`` (numpy -> numpy, torch.cuda -> torch.cuda), or of
         the reference rows ``[row_offset, row_offset + n_self_rows)`` when ``X`` is None.
         ``out=(dist, idx)``: contiguous float64 / int64 CUDA tensors of shape ``(nq, k)`` to write
-        into (torch.cuda input only), e.g. this rank's slot of an all-gather buffer."""
+        into (torch.cuda input only), e.g. this rank's slot of an all-gather buffer.
+        ``check_finite``: the kernels that read ``X`` also test it for NaN / infinity and the call
+        raises ``HipBackendError(ERR_NONFINITE)`` (for CUDA tensors this synchronises the stream)."""
         opts = self._opts(k, exclude_self=exclude_self, deterministic=deterministic,
                           decimals=decimals, formula=formula,
-                          apply_affine=apply_affine and X is not None, row_offset=row_offset)
+                          apply_affine=apply_affine and X is not None, row_offset=row_offset,
+                          check_finite=check_finite and X is not None)
         if X is None:
             if not exclude_self:
                 raise ValueError("X=None requires exclude_self=True")
@@ -112,11 +127,7 @@ class KNNEngine:
         if is_torch_cuda_tensor(X):
             import torch
 
-            if X.dtype != torch.float64 or not X.is_contiguous():
-                X = X.to(torch.float64).contiguous()
-            if X.device.index != self.device:
-                raise ValueError(f"X is on cuda:{X.device.index}, the engine on cuda:{self.device}")
-            self._check_columns(X, apply_affine)
+            X = self._as_device_rows(X, apply_affine)
             nq = X.shape[0]
             if out is not None:
                 dist, idx = out
@@ -136,6 +147,8 @@ class KNNEngine:
                 self._index.kneighbors_device(X.data_ptr(), nq, opts,
                                               dist.data_ptr() if dist is not None else 0,
                                               idx.data_ptr(), stream)
+                if check_finite:
+                    self._index.check_finite(stream)
             return dist, idx
         if out is not None:
             raise ValueError("out= is only supported for torch.cuda inputs")
@@ -144,7 +157,7 @@ class KNNEngine:
         return self._index.kneighbors_host(X, opts, return_distance=return_distance)
 
     def predict(self, X, k, weights="uniform", *, exclude_self=False, deterministic=True, decimals=10,
-                formula="expanded", apply_affine=False, row_offset=0, n_self_rows=None):
+                formula="expanded", apply_affine=False, row_offset=0, n_self_rows=None, check_finite=False):
         """Weighted multi-output mean of the neighbours' targets."""
         if self.t < 1:
             raise ValueError("the engine was built without targets")
@@ -153,7 +166,7 @@ class KNNEngine:
             # the callable map the (nq, k) distances to weights on the host, reduce on the GPU.
             dist, idx = self.kneighbors(X, k, exclude_self=exclude_self, deterministic=deterministic,
                                         decimals=decimals, formula=formula, apply_affine=apply_affine,
-                                        row_offset=row_offset, n_self_rows=n_self_rows)
+                                        row_offset=row_offset, n_self_rows=n_self_rows, check_finite=check_finite)
             if is_torch_cuda_tensor(dist):
                 import torch
 
@@ -174,25 +187,39 @@ class KNNEngine:
         mode = _WEIGHT_MODES[weights]
         opts = self._opts(k, exclude_self=exclude_self, deterministic=deterministic, decimals=decimals,
                           formula=formula, apply_affine=apply_affine and X is not None,
-                          weight_mode=mode, row_offset=row_offset)
+                          weight_mode=mode, row_offset=row_offset, check_finite=check_finite and X is not None)
         if X is None:
             nq = self.n_ref - row_offset if n_self_rows is None else int(n_self_rows)
             return self._index.predict_host(None, opts, nq=nq)
         if is_torch_cuda_tensor(X):
             import torch
 
-            if X.dtype != torch.float64 or not X.is_contiguous():
-                X = X.to(torch.float64).contiguous()
-            self._check_columns(X, apply_affine)
+            X = self._as_device_rows(X, apply_affine)
             nq = X.shape[0]
             pred = torch.empty((nq, self.t), dtype=torch.float64, device=X.device)
             if nq:
                 stream = torch.cuda.current_stream(X.device).cuda_stream
                 self._index.predict_device(X.data_ptr(), nq, opts, pred.data_ptr(), 0, 0, stream)
+                if check_finite:
+                    self._index.check_finite(stream)
             return pred
         X = np.ascontiguousarray(X, dtype=np.float64)
         self._check_columns(X, apply_affine)
         return self._index.predict_host(X, opts)
+
+    def open_stream(self, k, *, weights=None, want_dist=True, deterministic=True, decimals=10,
+                    formula="expanded", apply_affine=False, row_offset=0, check_finite=False):
+        """A :class:`sknnr_amd._native.QueryStream` over host tiles: ``push(tile)`` keeps the PCIe
+        pipeline full across tiles and carries the global row offset.  ``weights`` (``"uniform"`` /
+        ``"distance"``) also asks for predictions."""
+        want_pred = weights is not None
+        if want_pred and weights not in _WEIGHT_MODES:
+            raise ValueError("a stream predicts with 'uniform' or 'distance' weights only")
+        opts = self._opts(k, exclude_self=False, deterministic=deterministic, decimals=decimals,
+                          formula=formula, apply_affine=apply_affine,
+                          weight_mode=_WEIGHT_MODES[weights] if want_pred else _native.WEIGHTS_UNIFORM,
+                          row_offset=row_offset, check_finite=check_finite)
+        return self._index.open_stream(opts, want_dist=want_dist, want_pred=want_pred)
 
     def crosswalk(self, idx, table):
         """``table[idx]`` for int64 dataframe ids (REF _base.py:177-180)."""

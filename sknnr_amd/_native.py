@@ -29,6 +29,8 @@ ERR_NO_TARGETS = -3
 ERR_UNSUPPORTED = -4
 ERR_HIP = -5
 ERR_NO_DEVICE = -6
+ERR_NONFINITE = -7
+ABI_VERSION = 2
 
 # every symbol include/sknnr_hip.h declares (checked by tests/test_cabi.py)
 EXPORTED_SYMBOLS = (
@@ -42,9 +44,14 @@ EXPORTED_SYMBOLS = (
     "sknnr_index_shape",
     "sknnr_get_stats",
     "sknnr_reset_stats",
+    "sknnr_check_finite",
     "sknnr_kneighbors",
     "sknnr_predict",
     "sknnr_predict_from_neighbors",
+    "sknnr_stream_begin",
+    "sknnr_stream_push",
+    "sknnr_stream_flush",
+    "sknnr_stream_end",
     "sknnr_crosswalk",
     "sknnr_debug_coarse_matrix",
 )
@@ -59,7 +66,7 @@ class QueryOpts(ctypes.Structure):
         ("formula", c_int32),
         ("apply_affine", c_int32),
         ("weight_mode", c_int32),
-        ("reserved", c_int32),
+        ("check_finite", c_int32),
         ("row_offset", c_int64),
     ]
 
@@ -72,6 +79,9 @@ class Stats(ctypes.Structure):
         ("exact_only_queries", c_int64),
         ("last_kernel_ms", c_double),
         ("last_coarse_ms", c_double),
+        ("total_kernel_ms", c_double),
+        ("total_coarse_ms", c_double),
+        ("timed_calls", c_int64),
     ]
 
     def as_dict(self) -> dict:
@@ -116,8 +126,10 @@ def load(build_if_missing: bool = False):
                 "Run `python -m sknnr_amd._build` (needs hipcc); there is no CPU fallback."
             )
     lib = ctypes.CDLL(path)
-    if lib.sknnr_abi_version() != 1:
-        raise ImportError("libsknnr_hip.so ABI version mismatch")
+    if lib.sknnr_abi_version() != ABI_VERSION:
+        raise ImportError(
+            f"{path} has ABI version {lib.sknnr_abi_version()}, this package needs {ABI_VERSION}: "
+            "rebuild it with `python -m sknnr_amd._build --force`")
     vp = c_void_p
     lib.sknnr_device_count.restype = c_int32
     lib.sknnr_abi_version.restype = c_int32
@@ -131,6 +143,11 @@ def load(build_if_missing: bool = False):
                                       POINTER(c_int32), POINTER(c_int32)]
     lib.sknnr_get_stats.argtypes = [vp, POINTER(Stats)]
     lib.sknnr_reset_stats.argtypes = [vp]
+    lib.sknnr_check_finite.argtypes = [vp, vp]
+    lib.sknnr_stream_begin.argtypes = [vp, POINTER(QueryOpts), c_int32, c_int32, POINTER(vp)]
+    lib.sknnr_stream_push.argtypes = [vp, vp, c_int64, vp, vp, vp]
+    lib.sknnr_stream_flush.argtypes = [vp]
+    lib.sknnr_stream_end.argtypes = [vp, POINTER(c_int64)]
     lib.sknnr_kneighbors.argtypes = [vp, vp, c_int64, POINTER(QueryOpts), vp, vp, c_int32, vp]
     lib.sknnr_predict.argtypes = [vp, vp, c_int64, POINTER(QueryOpts), vp, vp, vp, c_int32, vp]
     lib.sknnr_predict_from_neighbors.argtypes = [vp, vp, vp, vp, c_int64, c_int32, c_int32, vp,
@@ -218,9 +235,19 @@ class Index:
 
     @staticmethod
     def make_opts(k, exclude_self=False, deterministic=True, decimals=10, formula=FORMULA_EXPANDED,
-                  apply_affine=False, weight_mode=WEIGHTS_UNIFORM, row_offset=0) -> QueryOpts:
+                  apply_affine=False, weight_mode=WEIGHTS_UNIFORM, row_offset=0,
+                  check_finite=False) -> QueryOpts:
         return QueryOpts(int(k), int(bool(exclude_self)), int(bool(deterministic)), int(decimals),
-                         int(formula), int(bool(apply_affine)), int(weight_mode), 0, int(row_offset))
+                         int(formula), int(bool(apply_affine)), int(weight_mode), int(bool(check_finite)),
+                         int(row_offset))
+
+    def check_finite(self, stream=0) -> None:
+        """Poll the non-finite-input flag of device-memory calls made with ``check_finite``
+        (synchronises ``stream``); raises :class:`HipBackendError` (``ERR_NONFINITE``)."""
+        check(load().sknnr_check_finite(self.handle, c_void_p(stream or None)))
+
+    def open_stream(self, opts: QueryOpts, want_dist=True, want_pred=False) -> "QueryStream":
+        return QueryStream(self, opts, want_dist, want_pred)
 
     # ---- host (numpy) entry points --------------------------------------------------------
     def kneighbors_host(self, q, opts: QueryOpts, nq=None, return_distance=True):
@@ -285,6 +312,78 @@ class Index:
         check(load().sknnr_debug_coarse_matrix(self.handle, _host_ptr(q), nq, _host_ptr(out),
                                                _host_ptr(qn), byref(s), byref(eps)))
         return out, qn, s.value, eps.value
+
+
+class QueryStream:
+    """Owner of one ``sknnr_stream*``: host tiles in, host results out, the PCIe pipeline kept full
+    across pushes (see include/sknnr_hip.h).  Output arrays handed to :meth:`push` are filled at the
+    latest when :meth:`flush` / :meth:`close` returns; the object keeps them alive until then."""
+
+    def __init__(self, index: Index, opts: QueryOpts, want_dist=True, want_pred=False):
+        self._index = index
+        self._h = c_void_p()
+        self._keep = []
+        self.k = opts.n_neighbors
+        self.want_dist, self.want_pred = bool(want_dist), bool(want_pred)
+        check(load().sknnr_stream_begin(index.handle, byref(opts), int(self.want_dist), int(self.want_pred),
+                                        byref(self._h)))
+
+    def push(self, q, out_idx=None, out_dist=None, out_pred=None, need_idx=True):
+        """Answer the rows of ``q``; returns the (idx, dist, pred) arrays that will hold the results
+        (the ones passed in, or fresh ones; ``need_idx=False`` with predictions skips the indices)."""
+        q = _c_f64(q)
+        nq = q.shape[0]
+        if out_idx is None and (need_idx or not self.want_pred):
+            out_idx = np.empty((nq, self.k), dtype=np.int64)
+        if out_dist is None and self.want_dist:
+            out_dist = np.empty((nq, self.k), dtype=np.float64)
+        if out_pred is None and self.want_pred:
+            out_pred = np.empty((nq, self._index.t), dtype=np.float64)
+        for a, dt, cols in ((out_idx, np.int64, self.k), (out_dist, np.float64, self.k),
+                            (out_pred, np.float64, self._index.t)):
+            if a is not None and (a.dtype != dt or not a.flags.c_contiguous or a.shape != (nq, cols)):
+                raise ValueError(f"output arrays must be C-contiguous ({nq}, {cols}) {np.dtype(dt)}")
+        check(load().sknnr_stream_push(self._h, _host_ptr(q), nq, _host_ptr(out_dist), _host_ptr(out_idx),
+                                       _host_ptr(out_pred)))
+        self._keep.append((out_idx, out_dist, out_pred))
+        if len(self._keep) > 4:
+            del self._keep[:-4]  # older tiles have left the two pipeline slots
+        return out_idx, out_dist, out_pred
+
+    def flush(self):
+        check(load().sknnr_stream_flush(self._h))
+        self._keep.clear()
+
+    def close(self) -> int:
+        """Flush and free; returns the number of rows pushed."""
+        if not self._h:
+            return 0
+        n = c_int64(0)
+        h, self._h = self._h, c_void_p()
+        code = load().sknnr_stream_end(h, byref(n))
+        self._keep.clear()
+        check(code)
+        return int(n.value)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if exc[0] is None:
+            self.close()
+        else:  # do not mask the original error
+            try:
+                self.close()
+            except HipBackendError:
+                pass
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().sknnr_stream_end(self._h, None)
+                self._h = c_void_p()
+        except Exception:
+            pass
 
 
 def affine_transform_host(x, center=None, scale=None, proj=None, device: int = 0) -> np.ndarray:

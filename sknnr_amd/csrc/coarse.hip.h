@@ -166,6 +166,10 @@ __device__ unsigned long long coarse_counters[16];
 #define SKNNR_PRIO_CORR 2
 #define SKNNR_PRIO_SCAN 2
 #endif
+#ifndef SKNNR_PRIO_MAIN
+#define SKNNR_PRIO_MAIN 1  // while the main products are issued
+#define SKNNR_PRIO_TEST 0  // skip test (and the rest of the sweep)
+#endif
 
 // 4 deep, flushed at 3; the 2-entry lists (one neighbour, four q-blocks per wave) make do with 2
 __host__ __device__ constexpr int queue_cap(int m) { return m == 2 ? 2 : 4; }
@@ -403,9 +407,9 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
             const int id_base = tile_no * 32 + 4 * half;
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
-                __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(SKNNR_PRIO_MAIN);
                 floatx16 acc = contract_main<KS>(ah, bh[qb], c0);
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(SKNNR_PRIO_TEST);
                 // Skip test: minima of five groups of the 16 main-product values ({0-2}, {3-5}, {6-8},
                 // {9-11}, {12-15}).  A value can only become a hit after correction if its main value is
                 // below thr + margin, so the same five minima later tell which groups to look at.
@@ -447,7 +451,7 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                             take_hit<M>(acc[r], id_base + acc_row(r, 0), vals[qb], idxs[qb], thr[qb], cnt[qb], qlane CTR_PASS);
                     }
                 }
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(SKNNR_PRIO_TEST);
                 TSTAMP(3);  // corrections + hit scan
                 if (__builtin_amdgcn_ballot_w64(cnt[qb] >= queue_flush_at(M)) != 0) {
                     CTR(6, 1);

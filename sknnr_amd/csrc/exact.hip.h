@@ -41,8 +41,24 @@ struct PrepArgs {
     double s;              // power-of-two scale of the coarse image
     double* xt;            // (nq, d) transformed rows out, or null
     uint4* qimg;           // [nq_pad/32][2][ks][64] fragments out, or null (transform only)
-    double* qnc;           // (nq) out
+    double* qnc;           // (nq) out; +inf marks a row whose image overflows f16 (never certified)
+    int* status;           // device word, or null: bit 0 = a query value is NaN, bit 1 = infinite
+                           // (SKL/utils/validation.py _assert_all_finite, reached from SKL/neighbors/_base.py:838-845)
 };
+
+// |b| at or above this has no finite f16 image (65504 is the largest f16; the margin keeps hi + lo exact)
+constexpr double kImageLimit = 32768.0;
+
+// Wave-level report of non-finite input values: one atomic per wave that saw any.
+__device__ __forceinline__ void report_nonfinite(int* status, bool has_nan, bool has_inf) {
+    if (!status) return;
+    const int bits = (has_nan ? 1 : 0) | (has_inf ? 2 : 0);
+    if (bits) atomicOr(status, bits);
+}
+__device__ __forceinline__ void classify(double v, bool& has_nan, bool& has_inf) {
+    has_nan |= v != v;
+    has_inf |= fabs(v) == INFINITY;
+}
 
 template <int BT>
 __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
@@ -59,8 +75,10 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
         // coalesced walk over the block's contiguous rows; (row, col) advanced incrementally
         int r = tid / a.d_in, c = tid - (tid / a.d_in) * a.d_in;
         const int dr = BT / a.d_in, dc = BT - dr * a.d_in;
+        bool has_nan = false, has_inf = false;
         for (long e = tid; e < n_el; e += BT) {
             double v = xsrc[e];
+            classify(v, has_nan, has_inf);
             if (a.center) v = v - a.center[c];
             if (a.scale) v = v / a.scale[c];
             xs[r * ldx + c] = v;
@@ -68,6 +86,7 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
             c += dc;
             if (c >= a.d_in) { c -= a.d_in; ++r; }
         }
+        report_nonfinite(a.status, has_nan, has_inf);
     }
     __syncthreads();
 
@@ -78,6 +97,7 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
     const int dp = 16 * a.ks;
     const double* xrow = xs + tid * ldx;
     double qn = 0.0;
+    bool overflow = false;
     for (int jc = 0; jc < 2 * a.ks; ++jc) {
         double acc[8];
 #pragma unroll
@@ -111,6 +131,7 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
         for (int jj = 0; jj < 8; ++jj) {
             const int k = jc * 8 + jj;
             const double b = (live && k < a.d) ? a.s * (acc[jj] - a.mu[k]) : 0.0;
+            overflow |= !(fabs(b) < kImageLimit);
             qn = fma(b, b, qn);
             const _Float16 h = (_Float16)(float)b;
             hi[jj] = h;
@@ -122,7 +143,7 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
             a.qimg[((size_t)(qb * 2 + 1) * a.ks + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, lo);
         }
     }
-    if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? qn : 0.0;
+    if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? (overflow ? INFINITY : qn) : 0.0;
 }
 
 // Register-resident variant for narrow feature spaces (16*KS <= 64 transformed features): one
@@ -139,6 +160,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
     double acc[DP];
 #pragma unroll
     for (int j = 0; j < DP; ++j) acc[j] = 0.0;
+    bool has_nan = false, has_inf = false;
     if (live) {
         const double* xr = a.x + q * a.d_in;
         if (a.proj) {
@@ -148,6 +170,8 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
                 for (; c < a.d_in; c += 2) {
                     const double2 xv = x2[c >> 1];
                     double v0 = xv.x, v1 = xv.y;
+                    classify(v0, has_nan, has_inf);
+                    classify(v1, has_nan, has_inf);
                     if (a.center) { v0 = v0 - a.center[c]; v1 = v1 - a.center[c + 1]; }
                     if (a.scale) { v0 = v0 / a.scale[c]; v1 = v1 / a.scale[c + 1]; }
                     const double* p0 = a.proj + (long)c * DP;
@@ -159,6 +183,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
             }
             for (; c < a.d_in; ++c) {
                 double v = xr[c];
+                classify(v, has_nan, has_inf);
                 if (a.center) v = v - a.center[c];
                 if (a.scale) v = v / a.scale[c];
                 const double* pc = a.proj + (long)c * DP;
@@ -170,6 +195,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
             for (int k = 0; k < DP; ++k) {
                 if (k < a.d) {
                     double v = xr[k];
+                    classify(v, has_nan, has_inf);
                     if (a.center) v = v - a.center[k];
                     if (a.scale) v = v / a.scale[k];
                     acc[k] = v;
@@ -177,6 +203,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
             }
         }
     }
+    report_nonfinite(a.status, has_nan, has_inf);
     if (a.xt) {
         // Transformed rows go out through a wave-private LDS tile (64 rows x 8 KS columns, two
         // passes) so that every store instruction writes whole 64..128-byte row segments instead of
@@ -203,6 +230,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
     const long qb = q >> 5;
     const int col = (int)(q & 31);
     double qn = 0.0;
+    bool overflow = false;
 #pragma unroll
     for (int jc = 0; jc < 2 * KS; ++jc) {
         half8 hi, lo;
@@ -210,6 +238,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
         for (int jj = 0; jj < 8; ++jj) {
             const int k = jc * 8 + jj;
             const double b = (live && k < a.d) ? a.s * (acc[k] - a.mu[k]) : 0.0;
+            overflow |= !(fabs(b) < kImageLimit);
             qn = fma(b, b, qn);
             const _Float16 h = (_Float16)(float)b;
             hi[jj] = h;
@@ -221,7 +250,15 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
             a.qimg[((size_t)(qb * 2 + 1) * KS + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, lo);
         }
     }
-    if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? qn : 0.0;
+    if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? (overflow ? INFINITY : qn) : 0.0;
+}
+
+// Finiteness scan of query rows that no prep kernel reads (calls outside the MFMA envelope).
+__global__ void __launch_bounds__(256) check_finite_kernel(const double* __restrict__ x, long n, int* status) {
+    bool has_nan = false, has_inf = false;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) classify(x[i], has_nan, has_inf);
+    report_nonfinite(status, has_nan, has_inf);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -319,8 +356,15 @@ struct FinalizeArgs {
     int m_list;             // entries per lane list written by the coarse kernel (<= M)
     const double* qnc;      // (nq)
     double inv_s2;          // 1 / s^2
+    double s2;              // s^2
+    double inv_s;           // 1 / s
     double eps_c;           // certificate: eps = eps_c * (sqrt(qnc) + ymax)^2 (already * 2^-24)
     double ymax;            // max |s (r - mu)|
+    // Rounding noise of the reference's own float64 expression: the value it ranks a
+    // pair by differs from the true squared distance by at most noise_a * (|x| + |y|)^2 for the expanded
+    // formula (uncentred norms: |x| <= |q'|/s + |mu|) and by noise_a * |x - y|^2 for the direct one (mu2 = 0).
+    double noise_a;         // (d + 4) * 2^-53
+    double mu2;             // 2 |mu| (expanded formula) or 0 (direct)
     int* fail_list;         // call-relative row ids of uncertified queries
     int fail_base;          // call-relative id of this launch's row 0
     int* fail_count;
@@ -471,7 +515,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         rank_c += (cj < cve) || (cj == cve && pj < c);
     });
     const double tau_c = group_min<LPQ>(rank_c >= s.kk - 1 ? (double)cve : INFINITY, c);
-    const bool need = valid && ((double)cv <= tau_c + 2.0 * eps);
+    // ... and the reference ranks by its rounded float64 expression: two rows closer than twice its noise
+    // may come out in either order, so the window widens by that much (in scaled units).
+    const double nr = nrm * a.inv_s + a.mu2;
+    const double noise = a.noise_a * nr * nr;
+    const bool need = valid && ((double)cv <= tau_c + 2.0 * eps + 2.0 * noise * a.s2);
 
     double d2 = INFINITY;
     if (need) d2 = pair_d2(s.xq + q * s.d, s.ref + (long)id * s.d, s.d, s.rn[id], s.formula);
@@ -500,7 +548,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const float cv_partner = __shfl(cv_raw, partner, LPQ);
     const double t_pair = (list == 0 && has_slot) ? (double)fminf(cv_raw, cv_partner) : -INFINITY;
     const double t_min = group_max<LPQ>(t_pair, c);
-    const double bound = (qn + t_min - eps) * a.inv_s2;
+    // true d2 of every outside row >= (qn + t_min - eps) / s^2; the value the reference ranks it by is at
+    // most `noise` below that.  qn = +inf (image overflow) and NaN inputs fail the comparison.
+    const double bound = (qn + t_min - eps) * a.inv_s2 - noise;
     bool certified = (n_usable >= s.kk) && (tau < INFINITY) && (bound > tau);
     // Exactly tied float64 distances: which tied row the reference keeps at the k-th slot (and,
     // without deterministic ordering, in which order it lists tied rows) depends on its heap's

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -99,6 +100,10 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }  // early returns (HIP_TRY) free what a function allocated
     hipError_t ensure(size_t count) {
         if (count <= n && p) return hipSuccess;
         if (p) (void)hipFree(p);
@@ -119,11 +124,20 @@ constexpr int kMaxKs = 8;              // coarse path: d <= 128
 constexpr long kRowQuantum = 6144;  // query-row padding: multiple of every coarse geometry (2048, 1536, 1024, 768, 512, 384, 256 rows per workgroup)
 constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk (each chunk is padded to kRowQuantum)
 constexpr int kScanMaxKK = 192;
-// Error budget of the split contraction, in units of 2^-24 (|q'| + max|r'|)^2:
-// eps_units(ks) = 8 + 4 ks.  Measured worst case on gfx950 over 5e5 pairs per shape
-// (scripts/gpu_probe.py, tests/test_hip_parity.py::test_coarse_error_budget): 2.6 (d=8),
-// 3.4 (16), 3.8 (32), 3.9 (64), 5.1 (100) -- the budget keeps >= 4x headroom.
-constexpr double eps_units(int ks) { return 8.0 + 4.0 * ks; }
+// Error bound of the split contraction, in units of 2^-24 (|q'| + max|r'|)^2 -- derived in DESIGN.md
+// section 2 from the measured arithmetic of v_mfma_f32_32x32x16_f16 (scripts/microbench/
+// mfma_f16_numerics.hip, profiles/r02_mfma_f16_numerics.txt: per instruction two groups of eight exact
+// products, each group aligned to its largest product and truncated 24 bits below it, each group sum
+// added with one round-to-nearest-even):
+//     6.01   dropped terms of the split  (lo.lo, and the residuals a - hi - lo, b - hi - lo)
+//   + 3.51   truncation inside the groups  (7 x 2^-24 x sum |products|, sum <= 2 |q'||r'| (1 + 2^-10))
+//   + 1.00   |r'|^2 rounded to f32 (the C operand)
+//   + 6 ks   two roundings per instruction, 3 ks instructions, each <= 2^-24 x |partial value|
+//   + 0.25   f16 subnormal floor of the lo parts
+// = 10.77 + 6 ks  ->  11 + 6 ks.  Random operands reach 2.6 (d=8) .. 5.1 (d=100) units
+// (tests/test_hip_parity.py::test_coarse_error_budget); adversarial ones (same-sign products at the
+// image limits, full mantissas) are tested in test_coarse_error_budget_adversarial.
+constexpr double eps_units(int ks) { return 11.0 + 6.0 * ks; }
 
 }  // namespace
 
@@ -138,7 +152,9 @@ struct sknnr_index {
     int n_stages = 0;
     double s = 1.0;   // coarse scale
     double ymax = 0.0;
+    double mu_norm = 0.0;    // |mu| (upper bound), for the reference formula's rounding-noise term
     std::vector<double> mu;  // (16*ks) zero padded
+    std::mutex mtx;          // one call at a time per handle (the workspace below is shared)
 
     // query-time affine map
     int d_in = 0;
@@ -155,6 +171,7 @@ struct sknnr_index {
     DevBuf<uint4> qimg;
     DevBuf<float> cand_val;
     DevBuf<int> cand_idx, fail_list, fail_count;
+    DevBuf<int> status;            // bit 0: a query value was NaN, bit 1: infinite (since the last poll)
     DevBuf<long long> fail_total;  // running count of certificate failures (device)
     DevBuf<long> idx_stage;
 
@@ -170,11 +187,24 @@ struct sknnr_index {
     } slot[2];
     hipStream_t st_h2d = nullptr, st_run = nullptr, st_d2h = nullptr;
 
-    hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
+    // Workspace hand-over between calls on different streams: the last launch of a call records
+    // ev_ws; the next call's stream waits for it before it touches the workspace.
+    hipEvent_t ev_ws = nullptr;
+    bool ws_busy = false;
+    bool stream_open = false;  // a sknnr_stream owns the host pipeline's slots
+
+    // Device timing of calls (HIP events on the launch stream), resolved lazily by sknnr_get_stats:
+    // a ring of call records so that several calls of one benchmark step are summed, not only the last.
+    struct CallTiming {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> coarse;
+        size_t coarse_used = 0;
+        bool pending = false;
+    };
+    static constexpr int kTimingRing = 64;
+    CallTiming timing[kTimingRing];
+    int timing_next = 0;
     sknnr_stats stats{};
-    bool timing_pending = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> coarse_events;
-    size_t coarse_events_used = 0;
 
     ~sknnr_index() {
         (void)hipSetDevice(device);
@@ -189,6 +219,7 @@ struct sknnr_index {
         fail_list.release();
         fail_count.release();
         fail_total.release();
+        status.release();
         idx_stage.release();
         for (auto& sl : slot) {
             for (void* hp : {(void*)sl.pin_x, (void*)sl.pin_d, (void*)sl.pin_i, (void*)sl.pin_p})
@@ -199,11 +230,14 @@ struct sknnr_index {
         }
         for (hipStream_t h : {st_h2d, st_run, st_d2h})
             if (h) (void)hipStreamDestroy(h);
-        for (hipEvent_t e : {ev_call0, ev_call1, ev_c0, ev_c1})
-            if (e) (void)hipEventDestroy(e);
-        for (auto& pr : coarse_events) {
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+        if (ev_ws) (void)hipEventDestroy(ev_ws);
+        for (auto& ct : timing) {
+            for (hipEvent_t e : {ct.e0, ct.e1})
+                if (e) (void)hipEventDestroy(e);
+            for (auto& pr : ct.coarse) {
+                (void)hipEventDestroy(pr.first);
+                (void)hipEventDestroy(pr.second);
+            }
         }
     }
 };
@@ -514,6 +548,11 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
                 }
         }
         ix->ymax = std::sqrt(ymax2);
+        {
+            double m2 = 0.0;
+            for (int c = 0; c < d; ++c) m2 += ix->mu[c] * ix->mu[c];
+            ix->mu_norm = std::sqrt(m2) * (1.0 + 1e-12);
+        }
         HIP_TRY(ix->rimg.ensure(img.size()));
         HIP_TRY(hipMemcpy(ix->rimg.p, img.data(), img.size(), hipMemcpyHostToDevice));
         HIP_TRY(ix->perm.ensure((size_t)n_ref));
@@ -525,8 +564,9 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
     HIP_TRY(ix->fail_count.ensure(4));
     HIP_TRY(ix->fail_total.ensure(2));
     HIP_TRY(hipMemset(ix->fail_total.p, 0, 16));
-    HIP_TRY(hipEventCreate(&ix->ev_call0));
-    HIP_TRY(hipEventCreate(&ix->ev_call1));
+    HIP_TRY(ix->status.ensure(4));
+    HIP_TRY(hipMemset(ix->status.p, 0, 16));
+    HIP_TRY(hipEventCreateWithFlags(&ix->ev_ws, hipEventDisableTiming));
     HIP_TRY(hipDeviceSynchronize());
     guard.p = nullptr;
     *out = ix;
@@ -648,23 +688,34 @@ extern "C" int sknnr_affine_transform(const double* x, int64_t n, int32_t d_in, 
 // ----------------------------------------------------------------------------------------
 // stats
 // ----------------------------------------------------------------------------------------
-static void resolve_timing(sknnr_index* ix) {
-    if (!ix->timing_pending) return;
-    ix->timing_pending = false;
-    if (hipEventSynchronize(ix->ev_call1) != hipSuccess) return;
+// Fold one finished call record into the stats (waits for the call if it is still running).
+static void resolve_call(sknnr_index* ix, sknnr_index::CallTiming& ct) {
+    if (!ct.pending) return;
+    ct.pending = false;
+    if (hipEventSynchronize(ct.e1) != hipSuccess) return;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ix->ev_call0, ix->ev_call1) == hipSuccess) ix->stats.last_kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, ct.e0, ct.e1) != hipSuccess) return;
     double cms = 0.0;
-    for (size_t i = 0; i < ix->coarse_events_used; ++i) {
+    for (size_t i = 0; i < ct.coarse_used; ++i) {
         float m = 0.f;
-        if (hipEventElapsedTime(&m, ix->coarse_events[i].first, ix->coarse_events[i].second) == hipSuccess) cms += m;
+        if (hipEventElapsedTime(&m, ct.coarse[i].first, ct.coarse[i].second) == hipSuccess) cms += m;
     }
+    ix->stats.last_kernel_ms = ms;
     ix->stats.last_coarse_ms = cms;
+    ix->stats.total_kernel_ms += ms;
+    ix->stats.total_coarse_ms += cms;
+    ix->stats.timed_calls += 1;
+}
+static void resolve_timing(sknnr_index* ix) {
+    // oldest first, so that last_* end up describing the newest call
+    for (int i = 0; i < sknnr_index::kTimingRing; ++i)
+        resolve_call(ix, ix->timing[(ix->timing_next + i) % sknnr_index::kTimingRing]);
 }
 
 extern "C" int sknnr_get_stats(const sknnr_index* cix, sknnr_stats* out) {
     if (!cix || !out) return fail(SKNNR_ERR_INVALID, "NULL argument");
     sknnr_index* ix = const_cast<sknnr_index*>(cix);
+    std::lock_guard<std::mutex> lock(ix->mtx);
     (void)hipSetDevice(ix->device);
     resolve_timing(ix);
     long long total = 0;
@@ -700,11 +751,35 @@ extern "C" int sknnr_get_stats(const sknnr_index* cix, sknnr_stats* out) {
 
 extern "C" int sknnr_reset_stats(sknnr_index* ix) {
     if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
-    (void)hipSetDevice(ix->device);
-    (void)hipDeviceSynchronize();
-    (void)hipMemset(ix->fail_total.p, 0, 16);
+    std::lock_guard<std::mutex> lock(ix->mtx);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(ix->fail_total.p, 0, 16));
+    for (auto& ct : ix->timing) ct.pending = false;
     ix->stats = sknnr_stats{};
     return SKNNR_OK;
+}
+
+static int nonfinite_error(int bits) {
+    if (bits & 1) return fail(SKNNR_ERR_NONFINITE, "Input X contains NaN.");
+    return fail(SKNNR_ERR_NONFINITE, "Input X contains infinity or a value too large for dtype('float64').");
+}
+
+// Read and clear the handle's non-finite flag; the caller has synchronised the stream that set it.
+static int poll_status(sknnr_index* ix) {
+    int bits = 0;
+    HIP_TRY(hipMemcpy(&bits, ix->status.p, sizeof bits, hipMemcpyDeviceToHost));
+    if (!bits) return SKNNR_OK;
+    HIP_TRY(hipMemset(ix->status.p, 0, 16));
+    return nonfinite_error(bits);
+}
+
+extern "C" int sknnr_check_finite(sknnr_index* ix, void* stream) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(ix->mtx);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return poll_status(ix);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -715,8 +790,9 @@ namespace {
 __global__ void add_counter_kernel(const int* __restrict__ cnt, long long* __restrict__ total) { *total += *cnt; }
 
 int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool affine, double* xt,
-                hipStream_t st) {
+                hipStream_t st, bool check_finite = false) {
     PrepArgs a{};
+    a.status = check_finite ? ix->status.p : nullptr;
     a.x = x;
     a.nq = nq;
     a.nq_pad = nq_pad;
@@ -901,6 +977,9 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     if (nq > 0x7fffffffL) return fail(SKNNR_ERR_UNSUPPORTED, "more than 2^31 - 1 query rows in one call");
     if (affine && ix->ks == 0)
         return fail(SKNNR_ERR_UNSUPPORTED, "d = %d > 128 with an affine map is outside the HIP envelope", ix->d);
+    // the previous call may have run on another stream: its last kernel must be done with the workspace
+    if (ix->ws_busy) HIP_TRY(hipStreamWaitEvent(st, ix->ev_ws, 0));
+    const bool check_finite = o->check_finite != 0 && xdev != nullptr;
 
     // transformed rows of the WHOLE call: the exact scan at the end reads any row of it
     const double* xq_call = self_rows ? ix->ref64.p + o->row_offset * ix->d : xdev;
@@ -939,25 +1018,39 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     call.out_dist = d_dist;
     call.out_idx = d_idx;
 
-    ix->coarse_events_used = 0;
-    HIP_TRY(hipEventRecord(ix->ev_call0, st));
+    // timing record of this call (a ring: an old record still pending is folded into the totals first)
+    sknnr_index::CallTiming& ct = ix->timing[ix->timing_next];
+    ix->timing_next = (ix->timing_next + 1) % sknnr_index::kTimingRing;
+    resolve_call(ix, ct);
+    if (!ct.e0) {
+        HIP_TRY(hipEventCreate(&ct.e0));
+        HIP_TRY(hipEventCreate(&ct.e1));
+    }
+    ct.coarse_used = 0;
+    HIP_TRY(hipEventRecord(ct.e0, st));
+    if (check_finite && !(coarse || affine)) {
+        // no prep kernel reads the rows on this path: scan them here
+        const long n_el = nq * (long)d_x;
+        check_finite_kernel<<<dim3((unsigned)std::min<long>((n_el + 255) / 256, 256L * 16)), dim3(256), 0, st>>>(xdev, n_el, ix->status.p);
+        HIP_TRY(hipGetLastError());
+    }
     for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
         const long n = std::min(kChunkRows, nq - c0);
         const long n_pad = (n + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
         const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
         if (coarse || affine) {
-            int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st);
+            int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st, check_finite);
             if (rc) return rc;
         }
         if (!coarse) continue;
 
-        if (ix->coarse_events_used == ix->coarse_events.size()) {
+        if (ct.coarse_used == ct.coarse.size()) {
             hipEvent_t e0, e1;
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
-            ix->coarse_events.emplace_back(e0, e1);
+            ct.coarse.emplace_back(e0, e1);
         }
-        auto& ev = ix->coarse_events[ix->coarse_events_used++];
+        auto& ev = ct.coarse[ct.coarse_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
         int rc = launch_coarse(ix, n_pad, coarse_list_len(kk), kk, st);
         if (rc) return rc;
@@ -976,8 +1069,12 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         f.qnc = ix->qnc.p;
         f.m_list = coarse_list_len(kk);
         f.inv_s2 = 1.0 / (ix->s * ix->s);
+        f.s2 = ix->s * ix->s;
+        f.inv_s = 1.0 / ix->s;
         f.eps_c = eps_units(ix->ks) * std::ldexp(1.0, -24);
         f.ymax = ix->ymax;
+        f.noise_a = (ix->d + 4) * std::ldexp(1.0, -53);
+        f.mu2 = o->formula == SKNNR_FORMULA_EXPANDED ? 2.0 * ix->mu_norm : 0.0;
         f.fail_list = ix->fail_list.p;
         f.fail_count = ix->fail_count.p;
         f.fail_base = (int)c0;
@@ -997,8 +1094,10 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     } else {
         ix->stats.exact_only_queries += nq;
     }
-    HIP_TRY(hipEventRecord(ix->ev_call1, st));
-    ix->timing_pending = true;
+    HIP_TRY(hipEventRecord(ct.e1, st));
+    ct.pending = true;
+    HIP_TRY(hipEventRecord(ix->ev_ws, st));
+    ix->ws_busy = true;
     ix->stats.queries += nq;
     return SKNNR_OK;
 }
@@ -1056,16 +1155,38 @@ int ensure_pinned(T*& p, size_t& have, size_t want) {
 }
 
 // Pageable host arrays in, pageable host arrays out, through two pinned/device slots:
-//   host thread : copy chunk c into pinned[c&1]            | copy results of chunk c-1 out
+//   host thread : copy tile c into pinned[c&1]             | copy results of tile c-2 out
 //   st_h2d      : pinned -> device                          (PCIe)
 //   st_run      : prep / pre-filter / finalise / scan [+ predict]
 //   st_d2h      : device -> pinned                          (PCIe)
-// so that PCIe in, kernels and PCIe out of neighbouring chunks overlap.
-int run_host_pipeline_impl(sknnr_index* ix, const double* q, long nq, const sknnr_query_opts* o, double* out_dist,
-                           long* out_idx, double* out_pred /* or null */) {
-    const int k = o->n_neighbors, t = ix->t;
-    const int d_x = o->apply_affine ? ix->d_in : ix->d;
-    const long cap = std::min(host_chunk_rows(), nq);
+// so that PCIe in, kernels and PCIe out of neighbouring tiles overlap.  The state lives in a HostPipe so
+// that the streamed entry points (sknnr_stream_*) keep the pipeline full ACROSS calls: a pushed tile's
+// results leave the slot when the slot is needed again (two pushes later) or at flush.
+struct HostPipe {
+    sknnr_index* ix = nullptr;
+    sknnr_query_opts o{};        // o.row_offset advances with every submitted tile
+    bool want_dist = false, want_idx = true, want_pred = false;
+    int k = 0, t = 0, d_x = 0;
+    struct Pending {
+        bool live = false;
+        long n = 0;
+        double* od = nullptr;
+        long* oi = nullptr;
+        double* op = nullptr;
+    } pending[2];
+    int slot_of = 0;
+};
+
+int pipe_open(HostPipe& p, sknnr_index* ix, const sknnr_query_opts* o, bool want_dist, bool want_idx, bool want_pred) {
+    p = HostPipe{};
+    p.ix = ix;
+    p.o = *o;
+    p.want_dist = want_dist;
+    p.want_idx = want_idx;
+    p.want_pred = want_pred;
+    p.k = o->n_neighbors;
+    p.t = ix->t;
+    p.d_x = o->apply_affine ? ix->d_in : ix->d;
     if (!ix->st_h2d) {
         HIP_TRY(hipStreamCreateWithFlags(&ix->st_h2d, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&ix->st_run, hipStreamNonBlocking));
@@ -1076,74 +1197,132 @@ int run_host_pipeline_impl(sknnr_index* ix, const double* q, long nq, const sknn
             HIP_TRY(hipEventCreateWithFlags(&sl.ev_d2h, hipEventDisableTiming));
         }
     }
-    const int n_slots = nq > cap ? 2 : 1;
-    for (int b = 0; b < n_slots; ++b) {
-        auto& sl = ix->slot[b];
-        int rc;
-        if ((rc = ensure_pinned(sl.pin_x, sl.pin_x_n, (size_t)cap * d_x))) return rc;
-        if (out_idx && (rc = ensure_pinned(sl.pin_i, sl.pin_i_n, (size_t)cap * k))) return rc;
-        if (out_dist && (rc = ensure_pinned(sl.pin_d, sl.pin_d_n, (size_t)cap * k))) return rc;
-        if (out_pred && (rc = ensure_pinned(sl.pin_p, sl.pin_p_n, (size_t)cap * t))) return rc;
-        HIP_TRY(sl.dev_x.ensure((size_t)cap * d_x));
-        HIP_TRY(sl.dev_i.ensure((size_t)cap * k));
-        HIP_TRY(sl.dev_d.ensure((size_t)cap * k));
-        if (out_pred) HIP_TRY(sl.dev_p.ensure((size_t)cap * t));
+    return SKNNR_OK;
+}
+
+// copy slot b's finished results to the caller's arrays
+int pipe_drain(HostPipe& p, int b) {
+    auto& pd = p.pending[b];
+    if (!pd.live) return SKNNR_OK;
+    auto& sl = p.ix->slot[b];
+    HIP_TRY(hipEventSynchronize(sl.ev_d2h));
+    if (pd.oi) parallel_copy(pd.oi, sl.pin_i, (size_t)pd.n * p.k * sizeof(long));
+    if (pd.od) parallel_copy(pd.od, sl.pin_d, (size_t)pd.n * p.k * sizeof(double));
+    if (pd.op) parallel_copy(pd.op, sl.pin_p, (size_t)pd.n * p.t * sizeof(double));
+    pd.live = false;
+    return SKNNR_OK;
+}
+
+// One tile of at most host_chunk_rows() rows.  `q` may be reused by the caller as soon as this returns.
+int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, double* op) {
+    sknnr_index* ix = p.ix;
+    const int b = p.slot_of;
+    p.slot_of ^= 1;
+    auto& sl = ix->slot[b];
+    int rc = pipe_drain(p, b);  // the slot's previous tile must have left before its buffers are reused
+    if (rc) return rc;
+    const int k = p.k, t = p.t, d_x = p.d_x;
+    if ((rc = ensure_pinned(sl.pin_x, sl.pin_x_n, (size_t)n * d_x))) return rc;
+    if ((rc = ensure_pinned(sl.pin_i, sl.pin_i_n, (size_t)n * k))) return rc;
+    if (p.want_dist && (rc = ensure_pinned(sl.pin_d, sl.pin_d_n, (size_t)n * k))) return rc;
+    if (p.want_pred && (rc = ensure_pinned(sl.pin_p, sl.pin_p_n, (size_t)n * t))) return rc;
+    HIP_TRY(sl.dev_x.ensure((size_t)n * d_x));
+    HIP_TRY(sl.dev_i.ensure((size_t)n * k));
+    HIP_TRY(sl.dev_d.ensure((size_t)n * k));
+    if (p.want_pred) HIP_TRY(sl.dev_p.ensure((size_t)n * t));
+
+    parallel_copy(sl.pin_x, q, (size_t)n * d_x * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(sl.dev_x.p, sl.pin_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, ix->st_h2d));
+    HIP_TRY(hipEventRecord(sl.ev_h2d, ix->st_h2d));
+    HIP_TRY(hipStreamWaitEvent(ix->st_run, sl.ev_h2d, 0));
+    rc = run_device(ix, sl.dev_x.p, n, &p.o, sl.dev_d.p, sl.dev_i.p, ix->st_run);
+    if (rc) return rc;
+    if (p.want_pred) {
+        rc = launch_predict(ix, sl.dev_d.p, sl.dev_i.p, nullptr, n, k, p.o.weight_mode, sl.dev_p.p, ix->st_run);
+        if (rc) return rc;
     }
-    struct Pending { long c0 = -1, n = 0; } pending[2];
-    auto drain = [&](int b) -> int {  // copy slot b's finished results to the caller's arrays
-        if (pending[b].c0 < 0) return SKNNR_OK;
-        auto& sl = ix->slot[b];
-        HIP_TRY(hipEventSynchronize(sl.ev_d2h));
-        const long c0 = pending[b].c0, n = pending[b].n;
-        if (out_idx) parallel_copy(out_idx + c0 * k, sl.pin_i, (size_t)n * k * sizeof(long));
-        if (out_dist) parallel_copy(out_dist + c0 * k, sl.pin_d, (size_t)n * k * sizeof(double));
-        if (out_pred) parallel_copy(out_pred + c0 * t, sl.pin_p, (size_t)n * t * sizeof(double));
-        pending[b].c0 = -1;
-        return SKNNR_OK;
-    };
-    int slot_of = 0;
-    for (long c0 = 0; c0 < nq; c0 += cap, slot_of ^= 1) {
-        const int b = slot_of;
+    HIP_TRY(hipEventRecord(sl.ev_done, ix->st_run));
+    HIP_TRY(hipStreamWaitEvent(ix->st_d2h, sl.ev_done, 0));
+    if (oi) HIP_TRY(hipMemcpyAsync(sl.pin_i, sl.dev_i.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, ix->st_d2h));
+    if (od) HIP_TRY(hipMemcpyAsync(sl.pin_d, sl.dev_d.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ix->st_d2h));
+    if (op) HIP_TRY(hipMemcpyAsync(sl.pin_p, sl.dev_p.p, (size_t)n * t * sizeof(double), hipMemcpyDeviceToHost, ix->st_d2h));
+    HIP_TRY(hipEventRecord(sl.ev_d2h, ix->st_d2h));
+    auto& pd = p.pending[b];
+    pd.live = true;
+    pd.n = n;
+    pd.od = od;
+    pd.oi = oi;
+    pd.op = op;
+    p.o.row_offset += n;
+    return SKNNR_OK;
+}
+
+// Submit `nq` rows in tiles of at most host_chunk_rows().
+int pipe_submit_rows(HostPipe& p, const double* q, long nq, double* od, long* oi, double* op) {
+    const long cap = host_chunk_rows();
+    for (long c0 = 0; c0 < nq; c0 += cap) {
         const long n = std::min(cap, nq - c0);
-        auto& sl = ix->slot[b];
-        int rc = drain(b);  // the slot's previous chunk must have left before its buffers are reused
+        int rc = pipe_submit(p, q + c0 * p.d_x, n, od ? od + c0 * p.k : nullptr, oi ? oi + c0 * p.k : nullptr,
+                             op ? op + c0 * p.t : nullptr);
         if (rc) return rc;
-        parallel_copy(sl.pin_x, q + c0 * d_x, (size_t)n * d_x * sizeof(double));
-        HIP_TRY(hipMemcpyAsync(sl.dev_x.p, sl.pin_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, ix->st_h2d));
-        HIP_TRY(hipEventRecord(sl.ev_h2d, ix->st_h2d));
-        HIP_TRY(hipStreamWaitEvent(ix->st_run, sl.ev_h2d, 0));
-        sknnr_query_opts oc = *o;
-        oc.row_offset = o->row_offset + c0;
-        rc = run_device(ix, sl.dev_x.p, n, &oc, sl.dev_d.p, sl.dev_i.p, ix->st_run);
-        if (rc) return rc;
-        if (out_pred) {
-            rc = launch_predict(ix, sl.dev_d.p, sl.dev_i.p, nullptr, n, k, o->weight_mode, sl.dev_p.p, ix->st_run);
-            if (rc) return rc;
-        }
-        HIP_TRY(hipEventRecord(sl.ev_done, ix->st_run));
-        HIP_TRY(hipStreamWaitEvent(ix->st_d2h, sl.ev_done, 0));
-        if (out_idx)
-            HIP_TRY(hipMemcpyAsync(sl.pin_i, sl.dev_i.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, ix->st_d2h));
-        if (out_dist)
-            HIP_TRY(hipMemcpyAsync(sl.pin_d, sl.dev_d.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ix->st_d2h));
-        if (out_pred)
-            HIP_TRY(hipMemcpyAsync(sl.pin_p, sl.dev_p.p, (size_t)n * t * sizeof(double), hipMemcpyDeviceToHost, ix->st_d2h));
-        HIP_TRY(hipEventRecord(sl.ev_d2h, ix->st_d2h));
-        pending[b].c0 = c0;
-        pending[b].n = n;
     }
-    for (int b = 0; b < 2; ++b) {
-        int rc = drain(b);
+    return SKNNR_OK;
+}
+
+// Everything submitted so far is in the caller's arrays when this returns; reports non-finite input.
+int pipe_flush(HostPipe& p) {
+    for (int i = 0; i < 2; ++i) {
+        int rc = pipe_drain(p, p.slot_of ^ i);  // older tile first
         if (rc) return rc;
+    }
+    if (p.o.check_finite) {
+        HIP_TRY(hipStreamSynchronize(p.ix->st_run));
+        return poll_status(p.ix);
     }
     return SKNNR_OK;
 }
 
 int run_host_pipeline(sknnr_index* ix, const double* q, long nq, const sknnr_query_opts* o, double* out_dist,
                       long* out_idx, double* out_pred) {
-    const int rc = run_host_pipeline_impl(ix, q, nq, o, out_dist, out_idx, out_pred);
-    if (rc) (void)hipDeviceSynchronize();  // nothing of a failed call may still be in flight on the slots
+    if (ix->stream_open) return fail(SKNNR_ERR_INVALID, "a query stream is open on this handle: end it first");
+    HostPipe p;
+    int rc = pipe_open(p, ix, o, out_dist != nullptr, true, out_pred != nullptr);
+    if (!rc) rc = pipe_submit_rows(p, q, nq, out_dist, out_idx, out_pred);
+    if (!rc) rc = pipe_flush(p);
+    if (rc) {
+        const std::string msg = g_last_error;
+        (void)hipDeviceSynchronize();  // nothing of a failed call may still be in flight on the slots
+        g_last_error = msg;
+    }
     return rc;
+}
+
+// X=None (the query rows are the handle's own reference rows, already on the device): only the results
+// travel.  Runs on the default stream, chunk by chunk.
+int run_self_rows(sknnr_index* ix, long nq, const sknnr_query_opts* o, double* out_dist, long* out_idx, double* out_pred) {
+    hipStream_t st = nullptr;
+    const int k = o->n_neighbors;
+    for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
+        const long n = std::min<long>(kChunkRows, nq - c0);
+        HIP_TRY(ix->dist_stage.ensure((size_t)n * k));
+        HIP_TRY(ix->idx_stage.ensure((size_t)n * k));
+        if (out_pred) HIP_TRY(ix->pred_stage.ensure((size_t)n * ix->t));
+        sknnr_query_opts oc = *o;
+        oc.row_offset = o->row_offset + c0;
+        int rc = run_device(ix, nullptr, n, &oc, ix->dist_stage.p, ix->idx_stage.p, st);
+        if (rc) return rc;
+        if (out_pred) {
+            rc = launch_predict(ix, ix->dist_stage.p, ix->idx_stage.p, nullptr, n, k, o->weight_mode, ix->pred_stage.p, st);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(out_pred + c0 * ix->t, ix->pred_stage.p, (size_t)n * ix->t * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        if (out_dist)
+            HIP_TRY(hipMemcpyAsync(out_dist + c0 * k, ix->dist_stage.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (out_idx)
+            HIP_TRY(hipMemcpyAsync(out_idx + c0 * k, ix->idx_stage.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SKNNR_OK;
 }
 
 }  // namespace
@@ -1156,36 +1335,12 @@ extern "C" int sknnr_kneighbors(sknnr_index* ix, const double* q, int64_t nq, co
     int rc = validate_call(ix, q, nq, o, out_idx);
     if (rc) return rc;
     if (nq == 0) return SKNNR_OK;
+    if (mem != SKNNR_MEM_DEVICE && mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    std::lock_guard<std::mutex> lock(ix->mtx);
     HIP_TRY(hipSetDevice(ix->device));
-    const int k = o->n_neighbors;
-    if (mem == SKNNR_MEM_DEVICE) {
-        return run_device(ix, q, nq, o, out_dist, (long*)out_idx, (hipStream_t)stream);
-    }
-    if (mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    if (mem == SKNNR_MEM_DEVICE) return run_device(ix, q, nq, o, out_dist, (long*)out_idx, (hipStream_t)stream);
     if (q) return run_host_pipeline(ix, q, nq, o, out_dist, (long*)out_idx, nullptr);
-    // X=None: the query rows are already on the device; only the results travel
-    hipStream_t st = nullptr;
-    const int d_x = ix->d;
-    for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
-        const long n = std::min<long>(kChunkRows, nq - c0);
-        const double* xdev = nullptr;
-        if (q) {
-            HIP_TRY(ix->xstage.ensure((size_t)n * d_x));
-            HIP_TRY(hipMemcpyAsync(ix->xstage.p, q + c0 * d_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, st));
-            xdev = ix->xstage.p;
-        }
-        HIP_TRY(ix->dist_stage.ensure((size_t)n * k));
-        HIP_TRY(ix->idx_stage.ensure((size_t)n * k));
-        sknnr_query_opts oc = *o;
-        oc.row_offset = o->row_offset + c0;
-        rc = run_device(ix, xdev, n, &oc, ix->dist_stage.p, ix->idx_stage.p, st);
-        if (rc) return rc;
-        if (out_dist)
-            HIP_TRY(hipMemcpyAsync(out_dist + c0 * k, ix->dist_stage.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(out_idx + c0 * k, ix->idx_stage.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    return SKNNR_OK;
+    return run_self_rows(ix, nq, o, out_dist, (long*)out_idx, nullptr);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1206,6 +1361,9 @@ static int launch_predict(sknnr_index* ix, const double* dist, const long* idx, 
     const long total = nq * ix->t;
     predict_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(a);
     HIP_TRY(hipGetLastError());
+    // the reduction may read the handle's staging buffers: it is now the workspace's last user
+    HIP_TRY(hipEventRecord(ix->ev_ws, st));
+    ix->ws_busy = true;
     return SKNNR_OK;
 }
 
@@ -1218,39 +1376,30 @@ extern "C" int sknnr_predict_from_neighbors(sknnr_index* ix, const double* dist,
     if (mode == SKNNR_WEIGHTS_DISTANCE && !dist) return fail(SKNNR_ERR_INVALID, "distance weights need dist");
     if (mode == SKNNR_WEIGHTS_EXPLICIT && !w) return fail(SKNNR_ERR_INVALID, "explicit weights need w");
     if (mode < 0 || mode > 2) return fail(SKNNR_ERR_INVALID, "unknown weight mode %d", mode);
+    if (mem != SKNNR_MEM_DEVICE && mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
     if (nq == 0) return SKNNR_OK;
+    std::lock_guard<std::mutex> lock(ix->mtx);
     HIP_TRY(hipSetDevice(ix->device));
     if (mem == SKNNR_MEM_DEVICE)
         return launch_predict(ix, dist, (const long*)idx, w, nq, k, mode, out_pred, (hipStream_t)stream);
     hipStream_t st = nullptr;
-    DevBuf<double> dd, dw, dout;
+    DevBuf<double> dd, dw, dout;  // freed by their destructors on every return path
     DevBuf<long> di;
-    int rc = SKNNR_OK;
-    do {
-        hipError_t e;
-        if ((e = di.ensure((size_t)nq * k)) != hipSuccess || (e = dout.ensure((size_t)nq * ix->t)) != hipSuccess) {
-            rc = fail(SKNNR_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
-            break;
-        }
-        (void)hipMemcpy(di.p, idx, (size_t)nq * k * sizeof(long), hipMemcpyHostToDevice);
-        if (dist) {
-            if ((e = dd.ensure((size_t)nq * k)) != hipSuccess) { rc = fail(SKNNR_ERR_HIP, "hipMalloc failed"); break; }
-            (void)hipMemcpy(dd.p, dist, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice);
-        }
-        if (w) {
-            if ((e = dw.ensure((size_t)nq * k)) != hipSuccess) { rc = fail(SKNNR_ERR_HIP, "hipMalloc failed"); break; }
-            (void)hipMemcpy(dw.p, w, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice);
-        }
-        rc = launch_predict(ix, dist ? dd.p : nullptr, di.p, w ? dw.p : nullptr, nq, k, mode, dout.p, st);
-        if (rc) break;
-        e = hipMemcpy(out_pred, dout.p, (size_t)nq * ix->t * sizeof(double), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(SKNNR_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
-    } while (0);
-    dd.release();
-    dw.release();
-    dout.release();
-    di.release();
-    return rc;
+    HIP_TRY(di.ensure((size_t)nq * k));
+    HIP_TRY(dout.ensure((size_t)nq * ix->t));
+    HIP_TRY(hipMemcpy(di.p, idx, (size_t)nq * k * sizeof(long), hipMemcpyHostToDevice));
+    if (dist) {
+        HIP_TRY(dd.ensure((size_t)nq * k));
+        HIP_TRY(hipMemcpy(dd.p, dist, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (w) {
+        HIP_TRY(dw.ensure((size_t)nq * k));
+        HIP_TRY(hipMemcpy(dw.p, w, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int rc = launch_predict(ix, dist ? dd.p : nullptr, di.p, w ? dw.p : nullptr, nq, k, mode, dout.p, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out_pred, dout.p, (size_t)nq * ix->t * sizeof(double), hipMemcpyDeviceToHost));
+    return SKNNR_OK;
 }
 
 extern "C" int sknnr_predict(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o, double* out_pred,
@@ -1267,6 +1416,8 @@ extern "C" int sknnr_predict(sknnr_index* ix, const double* q, int64_t nq, const
     int rc = validate_call(ix, q, nq, o, out_idx ? out_idx : &dummy_idx);
     if (rc) return rc;
     if (nq == 0) return SKNNR_OK;
+    if (mem != SKNNR_MEM_DEVICE && mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    std::lock_guard<std::mutex> lock(ix->mtx);
     HIP_TRY(hipSetDevice(ix->device));
     const int k = o->n_neighbors;
 
@@ -1274,6 +1425,10 @@ extern "C" int sknnr_predict(sknnr_index* ix, const double* q, int64_t nq, const
         hipStream_t st = (hipStream_t)stream;
         double* dd = out_dist;
         long* di = (long*)out_idx;
+        if (!dd || !di) {
+            // the staging buffers below belong to the workspace: wait for its previous user first
+            if (ix->ws_busy) HIP_TRY(hipStreamWaitEvent(st, ix->ev_ws, 0));
+        }
         if (!dd) {
             HIP_TRY(ix->dist_stage.ensure((size_t)nq * k));
             dd = ix->dist_stage.p;
@@ -1286,35 +1441,89 @@ extern "C" int sknnr_predict(sknnr_index* ix, const double* q, int64_t nq, const
         if (rc) return rc;
         return launch_predict(ix, dd, di, nullptr, nq, k, o->weight_mode, out_pred, st);
     }
-    if (mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
     if (q) return run_host_pipeline(ix, q, nq, o, out_dist, (long*)out_idx, out_pred);
-    hipStream_t st = nullptr;
-    const int d_x = ix->d;
-    for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
-        const long n = std::min<long>(kChunkRows, nq - c0);
-        const double* xdev = nullptr;
-        if (q) {
-            HIP_TRY(ix->xstage.ensure((size_t)n * d_x));
-            HIP_TRY(hipMemcpyAsync(ix->xstage.p, q + c0 * d_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, st));
-            xdev = ix->xstage.p;
-        }
-        HIP_TRY(ix->dist_stage.ensure((size_t)n * k));
-        HIP_TRY(ix->idx_stage.ensure((size_t)n * k));
-        HIP_TRY(ix->pred_stage.ensure((size_t)n * ix->t));
-        sknnr_query_opts oc = *o;
-        oc.row_offset = o->row_offset + c0;
-        rc = run_device(ix, xdev, n, &oc, ix->dist_stage.p, ix->idx_stage.p, st);
-        if (rc) return rc;
-        rc = launch_predict(ix, ix->dist_stage.p, ix->idx_stage.p, nullptr, n, k, o->weight_mode, ix->pred_stage.p, st);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out_pred + c0 * ix->t, ix->pred_stage.p, (size_t)n * ix->t * sizeof(double), hipMemcpyDeviceToHost, st));
-        if (out_dist)
-            HIP_TRY(hipMemcpyAsync(out_dist + c0 * k, ix->dist_stage.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, st));
-        if (out_idx)
-            HIP_TRY(hipMemcpyAsync(out_idx + c0 * k, ix->idx_stage.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+    return run_self_rows(ix, nq, o, out_dist, (long*)out_idx, out_pred);
+}
+
+// ----------------------------------------------------------------------------------------
+// streamed query tiles (raster ingestion)
+// ----------------------------------------------------------------------------------------
+struct sknnr_stream {
+    HostPipe pipe;
+    int64_t rows_pushed = 0;
+};
+
+extern "C" int sknnr_stream_begin(sknnr_index* ix, const sknnr_query_opts* o, int32_t want_dist, int32_t want_pred,
+                                  sknnr_stream** out) {
+    if (!out) return fail(SKNNR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    static int64_t dummy_idx;
+    static const double dummy_q = 0.0;
+    int rc = validate_call(ix, &dummy_q, 0, o, &dummy_idx);
+    if (rc) return rc;
+    if (o->exclude_self) return fail(SKNNR_ERR_INVALID, "a stream answers pushed rows: exclude_self is not available");
+    if (want_pred) {
+        if (ix->t < 1) return fail(SKNNR_ERR_NO_TARGETS, "the index was created without targets");
+        if (o->weight_mode != SKNNR_WEIGHTS_UNIFORM && o->weight_mode != SKNNR_WEIGHTS_DISTANCE)
+            return fail(SKNNR_ERR_INVALID, "a stream predicts with uniform or distance weights only");
     }
+    std::lock_guard<std::mutex> lock(ix->mtx);
+    if (ix->stream_open) return fail(SKNNR_ERR_INVALID, "a query stream is already open on this handle");
+    HIP_TRY(hipSetDevice(ix->device));
+    sknnr_stream* s = new (std::nothrow) sknnr_stream();
+    if (!s) return fail(SKNNR_ERR_INVALID, "out of host memory");
+    rc = pipe_open(s->pipe, ix, o, want_dist != 0, true, want_pred != 0);
+    if (rc) {
+        delete s;
+        return rc;
+    }
+    ix->stream_open = true;
+    *out = s;
     return SKNNR_OK;
+}
+
+extern "C" int sknnr_stream_push(sknnr_stream* s, const double* q, int64_t nq, double* out_dist, int64_t* out_idx,
+                                 double* out_pred) {
+    if (!s) return fail(SKNNR_ERR_INVALID, "stream is NULL");
+    if (nq < 0) return fail(SKNNR_ERR_INVALID, "nq must be >= 0");
+    if (nq == 0) return SKNNR_OK;
+    if (!q) return fail(SKNNR_ERR_INVALID, "q is NULL");
+    HostPipe& p = s->pipe;
+    if (!out_idx && !out_pred) return fail(SKNNR_ERR_INVALID, "a push needs out_idx or out_pred");
+    if (out_dist && !p.want_dist) return fail(SKNNR_ERR_INVALID, "the stream was opened without distances");
+    if (out_pred && !p.want_pred) return fail(SKNNR_ERR_INVALID, "the stream was opened without predictions");
+    std::lock_guard<std::mutex> lock(p.ix->mtx);
+    HIP_TRY(hipSetDevice(p.ix->device));
+    int rc = pipe_submit_rows(p, q, nq, out_dist, (long*)out_idx, out_pred);
+    if (rc) {
+        const std::string msg = g_last_error;
+        (void)hipDeviceSynchronize();
+        for (auto& pd : p.pending) pd.live = false;
+        g_last_error = msg;
+        return rc;
+    }
+    s->rows_pushed += nq;
+    return SKNNR_OK;
+}
+
+extern "C" int sknnr_stream_flush(sknnr_stream* s) {
+    if (!s) return fail(SKNNR_ERR_INVALID, "stream is NULL");
+    std::lock_guard<std::mutex> lock(s->pipe.ix->mtx);
+    HIP_TRY(hipSetDevice(s->pipe.ix->device));
+    return pipe_flush(s->pipe);
+}
+
+extern "C" int sknnr_stream_end(sknnr_stream* s, int64_t* rows_pushed) {
+    if (!s) return SKNNR_OK;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lock(s->pipe.ix->mtx);
+        rc = hipSetDevice(s->pipe.ix->device) == hipSuccess ? pipe_flush(s->pipe) : fail(SKNNR_ERR_HIP, "hipSetDevice failed");
+        s->pipe.ix->stream_open = false;
+    }
+    if (rows_pushed) *rows_pushed = s->rows_pushed;
+    delete s;
+    return rc;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1323,6 +1532,7 @@ extern "C" int sknnr_predict(sknnr_index* ix, const double* q, int64_t nq, const
 extern "C" int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int64_t* idx, int64_t n, int64_t* out,
                                int32_t device, int32_t mem, void* stream) {
     if (!table || !idx || !out || n < 0 || n_table < 1) return fail(SKNNR_ERR_INVALID, "bad argument");
+    if (mem != SKNNR_MEM_DEVICE && mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
     if (n == 0) return SKNNR_OK;
     HIP_TRY(hipSetDevice(device));
     const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 256L * 16);
@@ -1331,18 +1541,15 @@ extern "C" int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int6
         HIP_TRY(hipGetLastError());
         return SKNNR_OK;
     }
-    DevBuf<long> dt, di, dout;
+    DevBuf<long> dt, di, dout;  // freed by their destructors on every return path
     HIP_TRY(dt.ensure(n_table));
     HIP_TRY(di.ensure(n));
     HIP_TRY(dout.ensure(n));
-    (void)hipMemcpy(dt.p, table, n_table * sizeof(long), hipMemcpyHostToDevice);
-    (void)hipMemcpy(di.p, idx, n * sizeof(long), hipMemcpyHostToDevice);
+    HIP_TRY(hipMemcpy(dt.p, table, n_table * sizeof(long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(di.p, idx, n * sizeof(long), hipMemcpyHostToDevice));
     crosswalk_kernel<<<dim3(blocks), dim3(256)>>>(dt.p, di.p, n, dout.p);
-    hipError_t e = hipMemcpy(out, dout.p, n * sizeof(long), hipMemcpyDeviceToHost);
-    dt.release();
-    di.release();
-    dout.release();
-    if (e != hipSuccess) return fail(SKNNR_ERR_HIP, "crosswalk failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(long), hipMemcpyDeviceToHost));
     return SKNNR_OK;
 }
 

@@ -52,14 +52,16 @@ def test_no_other_symbols_leak(native):
 
 def test_abi_version_and_last_error(native):
     lib = native.load()
-    assert lib.sknnr_abi_version() == 1
+    assert lib.sknnr_abi_version() == native.ABI_VERSION == 2
     assert isinstance(lib.sknnr_last_error(), bytes)
 
 
 def test_struct_layouts_match_the_header(native):
     assert ctypes.sizeof(native.QueryOpts) == 40
     assert native.QueryOpts.row_offset.offset == 32
-    assert ctypes.sizeof(native.Stats) == 48
+    assert native.QueryOpts.check_finite.offset == 28
+    assert ctypes.sizeof(native.Stats) == 72
+    assert native.Stats.total_kernel_ms.offset == 48
 
 
 def test_argument_errors_without_touching_a_device(native):
@@ -67,6 +69,11 @@ def test_argument_errors_without_touching_a_device(native):
     assert lib.sknnr_index_create(None, 10, 3, None, 0, 0, ctypes.byref(ctypes.c_void_p())) == native.ERR_INVALID
     assert b"ref must be" in lib.sknnr_last_error()
     assert lib.sknnr_kneighbors(None, None, 1, None, None, None, 0, None) == native.ERR_INVALID
+    assert lib.sknnr_check_finite(None, None) == native.ERR_INVALID
+    assert lib.sknnr_stream_begin(None, None, 0, 0, ctypes.byref(ctypes.c_void_p())) == native.ERR_INVALID
+    assert lib.sknnr_stream_push(None, None, 1, None, None, None) == native.ERR_INVALID
+    assert lib.sknnr_stream_flush(None) == native.ERR_INVALID
+    assert lib.sknnr_stream_end(None, None) == 0  # NULL is allowed
     lib.sknnr_index_destroy(None)  # NULL is allowed
 
 
