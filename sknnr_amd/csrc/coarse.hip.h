@@ -437,7 +437,9 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
                     have_lo = true;
                 }
                 __builtin_amdgcn_s_setprio(SKNNR_PRIO_CORR);
+#ifndef SKNNR_ABLATE_NO_CORR  // timing experiment only: results are wrong without the corrections
                 acc = contract_correct<KS>(ah, al, bh[qb], bl[qb], acc);
+#endif
                 __builtin_amdgcn_s_setprio(SKNNR_PRIO_SCAN);
                 const unsigned qlane = qwave + qb * (queue_cap(M) * 512);
                 // (take_hit's compare is compiler-visible: it is the hazard-padded first reader of the

@@ -1,0 +1,389 @@
+// coarse2.hip.h -- second-generation MFMA pre-filter for narrow feature spaces (KS <= 2, lists of 6 / 8).
+//
+// Same contract as coarse_kernel (coarse.hip.h): for every query, the M smallest ranking values
+//   v(q, r) ~= |r'|^2 - 2 q'.r'   seen by each of the two lanes that own the query, with the J-th
+// smallest of both lists together (J = neighbours searched + 1) bounding every row that is not listed.
+// What changed, and why (measurements: DESIGN.md section 4, profiles/r02_*):
+//
+//   * On gfx950 a wave's VALU instructions overlap an MFMA only when they do not depend on it and sit
+//     behind it in the SAME wave's stream (about four per 32x32x16 MFMA are free; VALU of another wave
+//     of the SIMD is not overlapped, whatever the wave priorities).  The sweep is therefore software
+//     pipelined inside the wave: the main products of unit u+1 (a unit = one 32-reference tile x one
+//     32-query block) are issued first, then the skip test of unit u runs in their shadow.  The |r'|^2
+//     C operand is read from LDS straight into the accumulator registers, which pays for the second
+//     accumulator set.
+//   * The two correction products (lo.hi + hi.lo, four MFMAs per visited unit) are gone from the sweep.
+//     A unit is visited when some value's MAIN product is below threshold + margin (margin >= the size of
+//     the correction, as before); such values are queued with their main value, and the batched flush
+//     computes the correction of each queued entry exactly once with packed f16 dot products
+//     (v_dot2c_f32_f16) on the entry's fragments fetched from the image in L2 -- the two lanes that share
+//     a query each hold half of its K range and exchange partial sums.  Rejected values satisfy
+//     main >= threshold + margin, hence corrected >= threshold: the same guarantee the certificate uses.
+//   * LDS stages hold only hi fragments + |r'|^2 (16 tiles per stage: half the barriers).
+//   * Seeding: the first kSeedTiles tiles are swept once with a one-insertion-per-unit rule (each lane
+//     inserts its smallest main value) to obtain a valid starting threshold (J-th smallest seed value +
+//     margin); the real sweep then starts with a tight threshold instead of taking ~1000 hits per
+//     q-block in the first tiles.
+#pragma once
+#include "coarse.hip.h"
+
+namespace sknnr {
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int tile2_bytes(int ks) { return ks * 1024 + 128; }
+#ifndef SKNNR_V2_WAVES
+#define SKNNR_V2_WAVES 16
+#endif
+#ifndef SKNNR_V2_TPS
+#define SKNNR_V2_TPS (SKNNR_V2_WAVES == 16 ? 16 : 8)
+#endif
+// 16-wave workgroups: one per CU, 16 tiles per stage; 8-wave workgroups: two per CU (each with its own stages of
+// 8 tiles), so that a workgroup waiting at its stage barrier for a flushing wave leaves the SIMDs to the other one
+__host__ __device__ constexpr int tiles_per_stage2(int ks) { return ks <= 2 ? SKNNR_V2_TPS : SKNNR_V2_TPS / 2; }
+constexpr int kSeedTiles = 64;
+constexpr int kCoarse2Waves = SKNNR_V2_WAVES;
+constexpr int kCoarse2Nqb = 2;
+constexpr int kQueueCap = 5;      // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
+constexpr int kQueueFlushAt = 3;  // a visit ends with a flush once some lane holds this many
+__host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb * kQueueCap * 64 * 8; }
+__host__ __device__ constexpr bool coarse2_supported(int ks, int m) { return ks <= 2 && (m == 6 || m == 8); }
+
+// sum_j x[j] * y[j] over one 8-element fragment, f32 accumulate (v_dot2c_f32_f16)
+__device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const half2v p = {x[2 * i], x[2 * i + 1]}, q = {y[2 * i], y[2 * i + 1]};
+        acc = __builtin_amdgcn_fdot2(p, q, acc, false);
+    }
+    return acc;
+}
+
+// One pipelined step, hand scheduled (hipcc neither interleaves independent VALU work between dependent
+// MFMAs nor sees through the raw min instructions): the KS main MFMAs of the NEXT unit go out with the min
+// tree of the PREVIOUS unit's sixteen values placed behind them, about four VALU instructions per MFMA --
+// what the matrix pipe covers (scripts/microbench/mfma_shadow.hip).
+//   y        : accumulator of the next unit, holds |r'|^2 on entry (C operand in place)
+//   x[0..15] : main products of the previous unit (their MFMAs were issued one step ago)
+//   g[0..4]  : minima of {0-2}, {3-5}, {6-8}, {9-11}, {12-15};  m: minimum of all sixteen
+// Hazard (guide section 5.7): a VALU read of an MFMA result needs 11 wait states after the 8-pass MFMA was
+// issued and nothing pads the inside of an asm statement.  The second MFMA of the previous step was followed
+// by at least 6 VALU instructions of that step; `s_nop 4` supplies the remaining 5.
+#define SKNNR_TREE_A                                   \
+    "v_min3_f32 %[g0], %[x0], %[x1], %[x2]\n\t"        \
+    "v_min3_f32 %[g1], %[x3], %[x4], %[x5]\n\t"        \
+    "v_min3_f32 %[g2], %[x6], %[x7], %[x8]\n\t"        \
+    "v_min3_f32 %[g3], %[x9], %[x10], %[x11]\n\t"
+#define SKNNR_TREE_B                                   \
+    "v_min3_f32 %[g4], %[x12], %[x13], %[x14]\n\t"     \
+    "v_min3_f32 %[m], %[g0], %[g1], %[g2]\n\t"         \
+    "v_min_f32 %[g4], %[g4], %[x15]\n\t"               \
+    "s_nop 0\n\t"                                      \
+    "v_min3_f32 %[m], %[m], %[g3], %[g4]\n\t"
+#define SKNNR_TREE_OUT [g0] "=&v"(g[0]), [g1] "=&v"(g[1]), [g2] "=&v"(g[2]), [g3] "=&v"(g[3]), [g4] "=&v"(g[4]), [m] "=&v"(m)
+#define SKNNR_TREE_IN                                                                                             \
+    [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), \
+        [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]), [x12] "v"(x[12]),       \
+        [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[15])
+
+// The min tree alone (second unit of a tile: its MFMAs have just been issued).
+__device__ __forceinline__ void step_test_only(const floatx16& x, float (&g)[5], float& m) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\t" SKNNR_TREE_A SKNNR_TREE_B : SKNNR_TREE_OUT : SKNNR_TREE_IN);
+}
+// Both units of a tile, hand scheduled: the main MFMAs of the two units go out back to back and the min tree
+// of the FIRST unit sits behind the MFMAs of the second one -- independent VALU work in the shadow of the
+// wave's own MFMAs.  `c` holds |r'|^2 on entry and the second unit's values on exit (C operand in place).
+template <int KS>
+__device__ __forceinline__ void tile_issue_and_test(floatx16& a, floatx16& c, const half8 (&ah)[KS], const half8 (&p)[KS],
+                                                    const half8 (&q)[KS], float (&g)[5], float& m) {
+    static_assert(KS == 1 || KS == 2, "hand-scheduled for one or two K-steps");
+    if constexpr (KS == 2) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %[a], %[h0], %[p0], %[c]\n\t"
+                     "v_mfma_f32_32x32x16_f16 %[a], %[h1], %[p1], %[a]\n\t"
+                     "v_mfma_f32_32x32x16_f16 %[c], %[h0], %[q0], %[c]\n\t"
+                     "s_nop 3\n\t"  // (the third MFMA could only issue once the second had left the pipe)
+                     : [a] "=&v"(a), [c] "+v"(c)
+                     : [h0] "v"(ah[0]), [h1] "v"(ah[1]), [p0] "v"(p[0]), [p1] "v"(p[1]), [q0] "v"(q[0]));
+    } else {
+        asm volatile("v_mfma_f32_32x32x16_f16 %[a], %[h0], %[p0], %[c]\n\t"
+                     "v_mfma_f32_32x32x16_f16 %[c], %[h0], %[q0], %[c]\n\t"
+                     "s_nop 3\n\t"
+                     : [a] "=&v"(a), [c] "+v"(c)
+                     : [h0] "v"(ah[0]), [p0] "v"(p[0]), [q0] "v"(q[0]));
+    }
+    const floatx16& x = a;
+    asm volatile(SKNNR_TREE_A
+                 : [g0] "=&v"(g[0]), [g1] "=&v"(g[1]), [g2] "=&v"(g[2]), [g3] "=&v"(g[3])
+                 : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]),
+                   [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]));
+    if constexpr (KS == 2)
+        asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[h1], %[q1], %[c]\n\t" : [c] "+v"(c) : [h1] "v"(ah[1]), [q1] "v"(q[1]));
+    asm volatile("v_min3_f32 %[g4], %[x12], %[x13], %[x14]\n\t"
+                 "v_min3_f32 %[m], %[g0], %[g1], %[g2]\n\t"
+                 "v_min_f32 %[g4], %[g4], %[x15]\n\t"
+                 "s_nop 0\n\t"
+                 "v_min3_f32 %[m], %[m], %[g3], %[g4]\n\t"
+                 : [g4] "=&v"(g[4]), [m] "=&v"(m)
+                 : [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[15]), [g0] "v"(g[0]), [g1] "v"(g[1]),
+                   [g2] "v"(g[2]), [g3] "v"(g[3]));
+}
+
+template <int KS, int M>
+__global__ void __launch_bounds__(kCoarse2Waves * 64, 4)
+coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: KS KiB][|r'|^2: 128 B]
+               const char* __restrict__ rlo,    // n_stages * TPS records [lo: KS KiB]
+               int n_stages,
+               const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments
+               const double* __restrict__ qnc,  // [n_qblocks*32] |q'|^2 (0 for padding rows)
+               float skip_scale,                // 2^-9 * max|r'| * (1 + slack): margin = skip_scale * |q'|
+               int n_sentinel,                  // M - (neighbours searched + 1)
+               float* __restrict__ cand_val,    // [n_qblocks*32][2][M]
+               int* __restrict__ cand_idx) {
+    constexpr int TPS = tiles_per_stage2(KS);
+    constexpr int TB = tile2_bytes(KS);
+    constexpr int STAGE = TPS * TB;
+    constexpr int NQB = kCoarse2Nqb;
+    constexpr int WAVES = kCoarse2Waves;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const int qb0 = (blockIdx.x * WAVES + wave) * NQB;
+    const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue2_bytes_per_wave() + lane * 8);
+
+    // Queries of this wave: hi fragments resident for the whole sweep; the lo fragments are only needed by
+    // the flush, which fetches them again (16 VGPRs that the second accumulator set needs more).
+    half8 bh[NQB][KS];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            bh[qb][s] = __builtin_bit_cast(half8, qimg[((size_t)((qb0 + qb) * 2 + 0) * KS + s) * 64 + lane]);
+    }
+
+    float vals[NQB][M];
+    int idxs[NQB][M];
+#ifdef SKNNR_COARSE_COUNTERS
+    unsigned ctr[16] = {};
+#endif
+    float loose[NQB], margin[NQB];  // loose = threshold + margin: what a MAIN product is tested against
+    int cnt[NQB];                   // (a lane that had to drop hits sets its loose to NaN: nothing is below NaN, the
+                                    //  lane stops working and the query is marked at the end)
+    auto reset_lists = [&](int qb) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            vals[qb][i] = (half == 0 && i < n_sentinel) ? -FLT_MAX : FLT_MAX;
+            idxs[qb][i] = -1;
+        }
+    };
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        cnt[qb] = 0;
+        margin[qb] = skip_scale * (float)sqrt(qnc[(size_t)(qb0 + qb) * 32 + (lane & 31)]) + 1e-30f;
+        loose[qb] = FLT_MAX;
+        reset_lists(qb);
+    }
+
+    // ---- operands of one unit from the staged tile: |r'|^2 lands in the accumulator registers ------------
+    auto load_c0 = [&](const char* tb, floatx16& acc) {
+        const floatx4* cp = (const floatx4*)(tb + KS * 1024 + half * 64);
+        const floatx4 c_0 = cp[0], c_1 = cp[1], c_2 = cp[2], c_3 = cp[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] = c_0[i];
+            acc[4 + i] = c_1[i];
+            acc[8 + i] = c_2[i];
+            acc[12 + i] = c_3[i];
+        }
+    };
+    auto load_hi = [&](const char* tb, half8 (&ah)[KS]) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ah[s] = *(const half8*)(tb + s * 1024 + lane * 16);
+    };
+    auto issue_main = [&](const half8 (&ah)[KS], int qb, floatx16& acc) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[qb][s], acc, 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- flush: correct every queued entry, insert, tighten the pair's threshold ---------------------------
+    auto flush = [&](int qb) {
+        const unsigned qlane = qwave + qb * (kQueueCap * 512);
+        const int frag_off = (32 * half) * 16;  // this lane's K half inside a fragment row group
+        half8 bl[KS];  // this lane's lo fragments of the queries (not kept during the sweep)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            bl[s] = __builtin_bit_cast(half8, qimg[((size_t)((qb0 + qb) * 2 + 1) * KS + s) * 64 + lane]);
+        CTR(6, 1);
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt[qb]) != 0; ++i) {
+            CTR(7, 1);
+            CTR(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < cnt[qb])));
+            const bool active = i < cnt[qb];
+            unsigned long long e = 0;
+            if (active) e = queue_load(qlane + i * 512);
+            const float ev = __uint_as_float((unsigned)e);
+            const int pos_own = active ? (int)(e >> 32) : 0;
+            const int pos_par = __shfl_xor(pos_own, 32, 64);
+            // partial correction sums over this lane's K half, for its own entry and then for the partner's
+            // (one after the other: eight fragment registers at a time; 32-bit offsets from the uniform bases)
+            auto partial = [&](int pos) {
+                const unsigned row = (unsigned)(pos & 31) * 16u + (unsigned)frag_off;
+                const unsigned oh = (unsigned)(pos >> 5) * (unsigned)TB + row;
+                const unsigned ol = (unsigned)(pos >> 5) * (unsigned)(KS * 1024) + row;
+                float acc = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const half8 fl = *(const half8*)(rlo + ol + s * 1024);
+                    const half8 fh = *(const half8*)(rhi + oh + s * 1024);
+                    acc = dot8(fl, bh[qb][s], acc);
+                    acc = dot8(fh, bl[s], acc);
+                }
+                return acc;
+            };
+#ifdef SKNNR_V2_NO_CORR  // timing experiment: entries inserted with their main values
+            const float part_own = 0.f, part_par = (float)pos_par * 0.f;
+#else
+            const float part_own = partial(pos_own);
+            __builtin_amdgcn_sched_barrier(0);
+            const float part_par = partial(pos_par);
+#endif
+            const float from_partner = __shfl_xor(part_par, 32, 64);  // the partner's half of MY entry
+            const float cv = ev + (part_own + from_partner);
+            if (active && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, pos_own);
+        }
+        cnt[qb] = 0;
+        const float tight = pair_union_rank_m<M>(vals[qb]) + margin[qb];
+        loose[qb] = loose[qb] != loose[qb] ? loose[qb] : min2f(loose[qb], tight);  // (NaN = poisoned: stays)
+    };
+
+    // ---- one unit: skip test on the main products, visit = queue every value below threshold + margin ------
+    // The visit looks at the registers of the groups that can hold a hit and appends.  The queue is flushed at the END of a
+    // visit once a lane holds kQueueFlushAt entries, when the accumulator is dead and its registers are free
+    // for the flush's gathers; every visit therefore starts with at least kQueueCap - kQueueFlushAt + 1 free
+    // slots per lane.  A lane with more hits in ONE unit than it has room for (exact duplicates among the
+    // references, a query whose margin is infinite) poisons its query: the row fails the certificate and is
+    // answered by the exact scan.
+    auto process = [&](floatx16& acc, const float (&g)[5], float m1, int tile_no, int qb) {
+        CTR(0, 1);
+        if (__builtin_amdgcn_ballot_w64(m1 < loose[qb]) == 0) return;
+        CTR(1, 1);
+#ifdef SKNNR_V2_SWEEP_ONLY  // timing experiment: no visits (the margin keeps the sweep alive for the compiler)
+        margin[qb] += 1e-30f;
+        return;
+#endif
+        const unsigned qlane = qwave + qb * (kQueueCap * 512);
+        const int id_base = tile_no * 32 + 4 * half;
+        int want = cnt[qb];  // entries this lane would hold if the queue were unbounded
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (__builtin_amdgcn_ballot_w64(g[k] < loose[qb]) == 0) continue;
+#pragma unroll
+            for (int r = 3 * k; r < (k == 4 ? 16 : 3 * k + 3); ++r) {
+                const bool hit = acc[r] < loose[qb];
+                if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+                CTR(3, 1);
+                CTR(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(hit)));
+                want += hit ? 1 : 0;
+                if (hit && cnt[qb] < kQueueCap) {
+                    queue_store(qlane + cnt[qb] * 512, acc[r], id_base + acc_row(r, 0));
+                    cnt[qb] += 1;
+                }
+            }
+        }
+        if (want > kQueueCap) loose[qb] = __builtin_nanf("");
+        if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) flush(qb);
+    };
+
+    // ---- seeding: a valid starting threshold from the first kSeedTiles tiles ------------------------------
+    const int n_tiles = n_stages * TPS;
+#ifdef SKNNR_V2_NO_SEED
+    if (false) {
+#else
+    if (n_tiles >= 2 * kSeedTiles) {
+#endif
+        constexpr int SEED_STAGES = kSeedTiles / TPS;
+        stage_copy(rhi, smem, STAGE, wave, lane, WAVES);
+        __syncthreads();
+        for (int st = 0; st < SEED_STAGES; ++st) {
+            const char* cur = smem + (st & 1) * STAGE;
+            if (st + 1 < SEED_STAGES)
+                stage_copy(rhi + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
+#pragma unroll 1
+            for (int t = 0; t < TPS; ++t) {
+                const char* tb = cur + t * TB;
+                half8 ah[KS];
+                load_hi(tb, ah);
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) {
+                    floatx16 acc;
+                    load_c0(tb, acc);
+                    issue_main(ah, qb, acc);
+                    const float t0 = first_read(acc[0]);
+                    const float a0 = min3f(t0, acc[1], acc[2], t0), a1 = min3f(acc[3], acc[4], acc[5], t0);
+                    const float a2 = min3f(acc[6], acc[7], acc[8], t0), a3 = min3f(acc[9], acc[10], acc[11], t0);
+                    const float a4 = min2f(min3f(acc[12], acc[13], acc[14], t0), acc[15], t0);
+                    const float m1 = min3f(min3f(a0, a1, a2, t0), a3, a4, t0);
+                    if (__builtin_amdgcn_ballot_w64(m1 < vals[qb][M - 1]) != 0) {
+                        if (m1 < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], m1, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            // J distinct rows have main values <= the J-th smallest seed; their corrected values are at most
+            // `margin` larger: a valid bound on the J-th smallest corrected value of the whole sweep
+            const float seed = pair_union_rank_m<M>(vals[qb]);
+            loose[qb] = seed < FLT_MAX ? seed + 2.0f * margin[qb] : FLT_MAX;
+            reset_lists(qb);
+        }
+    }
+
+    // ---- the sweep ---------------------------------------------------------------------------------------------
+    stage_copy(rhi, smem, STAGE, wave, lane, WAVES);
+    __syncthreads();
+    for (int st = 0; st < n_stages; ++st) {
+        const char* cur = smem + (st & 1) * STAGE;
+        if (st + 1 < n_stages)
+            stage_copy(rhi + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
+        float g[5], m1;
+#pragma unroll 1
+        for (int t = 0; t < TPS; ++t) {
+            const char* tb = cur + t * TB;
+            const int tile_no = st * TPS + t;
+            floatx16 acc0, acc1;
+            half8 ah[KS];
+            load_hi(tb, ah);
+            load_c0(tb, acc1);
+            tile_issue_and_test<KS>(acc0, acc1, ah, bh[0], bh[1], g, m1);  // both units go out, unit 0 is tested
+            process(acc0, g, m1, tile_no, 0);
+            step_test_only(acc1, g, m1);
+            process(acc1, g, m1, tile_no, 1);
+        }
+        __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
+    }
+
+#ifdef SKNNR_COARSE_COUNTERS
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&coarse_counters[i], (unsigned long long)ctr[i]);
+#endif
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        flush(qb);
+        const size_t q = (size_t)(qb0 + qb) * 32 + (lane & 31);
+        const size_t base = (q * 2 + half) * M;
+        // a poisoned query (dropped hits) must fail the certificate: a NaN bound never certifies
+        const int mine = loose[qb] != loose[qb] ? 1 : 0;
+        const bool bad = (mine | __shfl_xor(mine, 32, 64)) != 0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cand_val[base + i] = bad ? __builtin_nanf("") : vals[qb][i];
+            cand_idx[base + i] = idxs[qb][i];
+        }
+    }
+}
+
+}  // namespace sknnr

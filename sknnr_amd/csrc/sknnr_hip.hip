@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "coarse.hip.h"
+#include "coarse2.hip.h"
 #include "exact.hip.h"
 
 using namespace sknnr;
@@ -138,6 +139,10 @@ constexpr int kScanMaxKK = 192;
 // (tests/test_hip_parity.py::test_coarse_error_budget); adversarial ones (same-sign products at the
 // image limits, full mantissas) are tested in test_coarse_error_budget_adversarial.
 constexpr double eps_units(int ks) { return 11.0 + 6.0 * ks; }
+// coarse2_kernel: only the ks main instructions round in the matrix pipe (2 ks roundings); the correction is a
+// packed-f16 dot product in f32 whose own rounding is below 0.1 unit, added with one more rounding:
+//   6.01 + 3.51 + 1.00 + (2 ks + 1) + 0.25 + 0.1 = 11.87 + 2 ks  ->  12 + 2 ks.
+constexpr double eps_units2(int ks) { return 12.0 + 2.0 * ks; }
 
 }  // namespace
 
@@ -164,6 +169,8 @@ struct sknnr_index {
 
     DevBuf<double> ref64, refT, rn64, y64, mu_dev;  // refT: (d, n_ref) transposed copy for the exact scan
     DevBuf<char> rimg;
+    DevBuf<char> rhi2, rlo2;  // coarse2_kernel's image: [hi | |r'|^2] records for the LDS stages, lo fragments apart
+    int n_stages2 = 0;
     DevBuf<int> perm;  // image position -> reference row (rows are imaged by increasing centred norm)
 
     // workspace (one chunk)
@@ -548,6 +555,30 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
                 }
         }
         ix->ymax = std::sqrt(ymax2);
+        if (ks <= 2) {
+            // second-generation kernel: hi fragments + |r'|^2 per tile (staged through LDS), lo fragments in an
+            // array of their own (read from L2 by the flush only)
+            const int tps2 = tiles_per_stage2(ks);
+            const long n_tiles2 = ((n_ref + 31) / 32 + tps2 - 1) / tps2 * tps2;
+            ix->n_stages2 = (int)(n_tiles2 / tps2);
+            const size_t tb2 = tile2_bytes(ks), lob = (size_t)ks * 1024;
+            std::vector<char> hi2(n_tiles2 * tb2, 0), lo2(n_tiles2 * lob, 0);
+            for (long tile = 0; tile < n_tiles2; ++tile) {
+                float* c2 = reinterpret_cast<float*>(hi2.data() + tile * tb2 + lob);
+                if (tile < n_tiles) {
+                    const char* rec = img.data() + tile * tb;
+                    std::memcpy(hi2.data() + tile * tb2, rec, lob);
+                    std::memcpy(lo2.data() + tile * lob, rec + lob, lob);
+                    std::memcpy(c2, rec + tile_frag_bytes(ks), 128);
+                } else {
+                    for (int i = 0; i < 32; ++i) c2[i] = std::numeric_limits<float>::infinity();
+                }
+            }
+            HIP_TRY(ix->rhi2.ensure(hi2.size()));
+            HIP_TRY(hipMemcpy(ix->rhi2.p, hi2.data(), hi2.size(), hipMemcpyHostToDevice));
+            HIP_TRY(ix->rlo2.ensure(lo2.size()));
+            HIP_TRY(hipMemcpy(ix->rlo2.p, lo2.data(), lo2.size(), hipMemcpyHostToDevice));
+        }
         {
             double m2 = 0.0;
             for (int c = 0; c < d; ++c) m2 += ix->mu[c] * ix->mu[c];
@@ -855,6 +886,42 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
     return SKNNR_OK;
 }
 
+template <int KS, int M>
+int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
+    constexpr int QPB = kCoarse2Waves * kCoarse2Nqb * 32;
+    constexpr size_t sh = 2 * (size_t)tiles_per_stage2(KS) * tile2_bytes(KS) + (size_t)kCoarse2Waves * queue2_bytes_per_wave();
+    static_assert(kRowQuantum % QPB == 0, "query rows are padded to multiples of kRowQuantum");
+    static_assert(sh <= 160 * 1024, "LDS budget");
+    auto kern = coarse2_kernel<KS, M>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(kCoarse2Waves * 64), sh, st>>>(
+        ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
+        M - (kk + 1), ix->cand_val.p, ix->cand_idx.p);
+    HIP_TRY(hipGetLastError());
+    return SKNNR_OK;
+}
+
+// The second-generation kernel serves ks <= 2 with lists of 6 or 8 (SKNNR_COARSE_V2=0 selects the first one).
+bool use_coarse2(const sknnr_index* ix, int m_list) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("SKNNR_COARSE_V2");
+        return !(e && std::atoi(e) == 0);
+    }();
+    // (small reference sets keep the first kernel: the second one needs its seeding pass -- without a starting
+    // threshold the first tiles give every lane more hits per unit than its queue holds)
+    // (and the flush addresses the image with 32-bit offsets)
+    const long tiles2 = (long)ix->n_stages2 * tiles_per_stage2(ix->ks);
+    return enabled && tiles2 >= 2 * kSeedTiles && tiles2 * tile2_bytes(ix->ks) < (1L << 32) && coarse2_supported(ix->ks, m_list);
+}
+
+int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
+    if (ix->ks == 1 && m_list == 6) return launch_coarse2_ks<1, 6>(ix, nq_pad, kk, st);
+    if (ix->ks == 1 && m_list == 8) return launch_coarse2_ks<1, 8>(ix, nq_pad, kk, st);
+    if (ix->ks == 2 && m_list == 6) return launch_coarse2_ks<2, 6>(ix, nq_pad, kk, st);
+    if (ix->ks == 2 && m_list == 8) return launch_coarse2_ks<2, 8>(ix, nq_pad, kk, st);
+    return fail(SKNNR_ERR_UNSUPPORTED, "no second-generation coarse kernel for ks = %d, list length %d", ix->ks, m_list);
+}
+
 // List length per lane for kk neighbours searched: at least one spare slot keeps the certificate
 // cheap.  kk > 31 is outside the MFMA envelope (exact scan for the whole call).
 constexpr int kCoarseMaxKK = 31;
@@ -1052,7 +1119,9 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         }
         auto& ev = ct.coarse[ct.coarse_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
-        int rc = launch_coarse(ix, n_pad, coarse_list_len(kk), kk, st);
+        const bool v2 = use_coarse2(ix, coarse_list_len(kk));
+        int rc = v2 ? launch_coarse2(ix, n_pad, coarse_list_len(kk), kk, st)
+                    : launch_coarse(ix, n_pad, coarse_list_len(kk), kk, st);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev.second, st));
 
@@ -1071,7 +1140,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         f.inv_s2 = 1.0 / (ix->s * ix->s);
         f.s2 = ix->s * ix->s;
         f.inv_s = 1.0 / ix->s;
-        f.eps_c = eps_units(ix->ks) * std::ldexp(1.0, -24);
+        f.eps_c = (v2 ? eps_units2(ix->ks) : eps_units(ix->ks)) * std::ldexp(1.0, -24);
         f.ymax = ix->ymax;
         f.noise_a = (ix->d + 4) * std::ldexp(1.0, -53);
         f.mu2 = o->formula == SKNNR_FORMULA_EXPANDED ? 2.0 * ix->mu_norm : 0.0;
