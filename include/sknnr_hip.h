@@ -59,8 +59,18 @@ typedef enum sknnr_memspace {
 typedef enum sknnr_formula {
     SKNNR_FORMULA_EXPANDED = 0, /* "brute"/ArgKmin: |x|^2 - 2 x.y + |y|^2, clamped at 0
                                    (SKL/metrics/_pairwise_distances_reduction/_argkmin.pyx.tp:492-502) */
-    SKNNR_FORMULA_DIRECT = 1    /* "kd_tree" (D <= 15): sum (x - y)^2
+    SKNNR_FORMULA_DIRECT = 1,   /* "kd_tree" (D <= 15): sum (x - y)^2
                                    (SKL/metrics/_dist_metrics.pxd.tp:39-57) */
+    SKNNR_FORMULA_HAMMING = 2   /* RFNN / GBNN: weighted Hamming distance of tree node ids,
+                                   sum_t w_t [a_t != b_t] / sum_t w_t, as scipy's cdist(metric="hamming", w=w)
+                                   evaluates it on the float64 ids (sums in tree order), reached from
+                                   REF _weighted_trees.py:53-59 (algorithm="brute", metric="hamming") and
+                                   :139-140 (metric_params={"w": hamming_weights_}) through
+                                   SKL/neighbors/_base.py:896-926 (pairwise_distances_chunked +
+                                   _kneighbors_reduce_func).  No square root; rows tied exactly at the k-th
+                                   distance are taken lowest index first (numpy's argpartition leaves that
+                                   choice to its introselect: INTEGRATION.md, "Hamming ties").  Needs
+                                   sknnr_index_set_hamming_weights. */
 } sknnr_formula;
 
 typedef enum sknnr_weight_mode {
@@ -139,6 +149,14 @@ void sknnr_index_destroy(sknnr_index* index);
  */
 int sknnr_index_set_affine(sknnr_index* index, int32_t d_in, const double* center,
                            const double* scale, const double* proj);
+
+/*
+ * Weights of the weighted-Hamming distance (one per column of the node-id matrix; finite, >= 0, not all 0).
+ * Replaces metric_params={"w": self.hamming_weights_} (REF _weighted_trees.py:139-140).  The index then
+ * holds node ids (float64 copies of the int64 ids the transformers emit, REF
+ * transformers/_tree_node_transformer.py:177-201) and answers opts->formula = SKNNR_FORMULA_HAMMING.
+ */
+int sknnr_index_set_hamming_weights(sknnr_index* index, const double* w, int32_t n);
 
 /*
  * The same affine map as a stand-alone call (no handle): out = ((x - center) / scale) @ proj.

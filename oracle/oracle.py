@@ -56,6 +56,9 @@ def _load():
             _f64p, ctypes.c_int64, _f64p, ctypes.c_int64, ctypes.c_int32,
             ctypes.c_int32, ctypes.c_int32, _f64p, _i64p,
         ]
+    lib.oracle_argkmin_hamming.argtypes = [
+        _f64p, ctypes.c_int64, _f64p, ctypes.c_int64, ctypes.c_int32, _f64p, ctypes.c_int32, _f64p, _i64p,
+    ]
     _lib = lib
     return lib
 
@@ -117,6 +120,38 @@ def argkmin(Q, R, k: int, formula: str = "expanded", squared: bool = False):
     fn = {"expanded": "oracle_argkmin_expanded", "direct": "oracle_argkmin_direct"}[formula]
     getattr(_load(), fn)(_ptr(Q), nq, _ptr(R), nr, d, k, int(squared), _ptr(dist),
                          _ptr(idx, _i64p))
+    return dist, idx
+
+
+def argkmin_hamming(Q, R, w, k: int):
+    """k smallest weighted-Hamming distances (see ``oracle_argkmin_hamming`` in knn_oracle.c); rows
+    ordered by (distance, index).  Q, R: node-id matrices (any integer / float dtype)."""
+    Q, R, w = _c64(Q), _c64(R), _c64(w).reshape(-1)
+    nq, d = Q.shape
+    nr = R.shape[0]
+    if R.shape[1] != d or w.size != d:
+        raise ValueError("feature mismatch")
+    if not 1 <= k <= nr:
+        raise ValueError(f"k={k} out of range for n_ref={nr}")
+    dist = np.empty((nq, k), dtype=np.float64)
+    idx = np.empty((nq, k), dtype=np.int64)
+    _load().oracle_argkmin_hamming(_ptr(Q), nq, _ptr(R), nr, d, _ptr(w), k, _ptr(dist), _ptr(idx, _i64p))
+    return dist, idx
+
+
+def kneighbors_hamming(fit_ids, ids=None, w=None, k: int = 5, deterministic: bool = True, decimals: int = 10,
+                       row_offset: int = 0):
+    """``RawKNNRegressor.kneighbors`` of the RFNN / GBNN estimators: weighted Hamming distance on node
+    ids, X=None drop-self, sknnr's reorder (REF _weighted_trees.py:53-59, _base.py:111-182)."""
+    fit_ids = _c64(fit_ids)
+    n_fit = fit_ids.shape[0]
+    if ids is None:
+        dist, idx = argkmin_hamming(fit_ids, fit_ids, w, k + 1)
+        dist, idx = drop_self(dist, idx)
+    else:
+        dist, idx = argkmin_hamming(ids, fit_ids, w, k)
+    if deterministic:
+        dist, idx = deterministic_reorder(dist, idx, decimals, row_offset)
     return dist, idx
 
 

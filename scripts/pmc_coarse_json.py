@@ -17,7 +17,7 @@ grid_max = 0
 recs = []
 for f in glob.glob(pmc_dir + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "coarse_kernel" in r["Kernel_Name"]:
+        if "coarse" in r["Kernel_Name"] and "matrix" not in r["Kernel_Name"]:
             recs.append(r)
             grid_max = max(grid_max, int(r["Grid_Size"]))
 name = None
@@ -28,7 +28,7 @@ for r in recs:
 avg = {k: sum(v) / len(v) for k, v in vals.items()}
 durs = []
 for r in csv.DictReader(open(trace_csv)):
-    if "coarse_kernel" in r["Kernel_Name"]:
+    if "coarse" in r["Kernel_Name"] and "matrix" not in r["Kernel_Name"]:
         durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 big = [d for d in durs if d > 0.8 * max(durs)]
 ms = sum(big) / len(big) / 1e6

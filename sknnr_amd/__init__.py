@@ -1,6 +1,6 @@
 """sknnr_amd -- MI355X-native backend for sknnr's kneighbors()/predict() hot path.
 
-Same estimator surface as lemma-osu/sknnr's Euclidean family; the arithmetic runs in
+Same estimator surface as lemma-osu/sknnr (Euclidean family and the tree-node family); the arithmetic runs in
 hand-written HIP kernels for gfx950 behind the C ABI of ``include/sknnr_hip.h``.
 Importing the package is cheap and works without a GPU; fitting or querying an
 estimator needs the built library and an MI355X (there is no CPU fallback).
@@ -14,7 +14,9 @@ from ._estimators import (
     MSNRegressor,
 )
 
-__version__ = "0.1.0"
+from ._forest_nn import GBNNRegressor, RFNNRegressor
+
+__version__ = "0.2.0"
 
 __all__ = [
     "RawKNNRegressor",
@@ -22,4 +24,6 @@ __all__ = [
     "MahalanobisKNNRegressor",
     "MSNRegressor",
     "GNNRegressor",
+    "RFNNRegressor",
+    "GBNNRegressor",
 ]

@@ -32,8 +32,14 @@ _ALGORITHMS = {"auto", "brute", "kd_tree", "ball_tree"}
 
 
 def _effective_metric(metric, p, metric_params):
-    """Only the Euclidean metric exists on the device (SKL/neighbors/_base.py:429-472 maps
-    minkowski/p=2 to 'euclidean')."""
+    """The Euclidean metric (SKL/neighbors/_base.py:429-472 maps minkowski/p=2 to 'euclidean') and the
+    weighted Hamming metric of the tree-based estimators (REF _weighted_trees.py:53-59) exist on the
+    device."""
+    if metric == "hamming":
+        extra = set(metric_params or {}) - {"w"}
+        if extra:
+            raise NotImplementedError(f"metric_params {sorted(extra)} are not supported with metric='hamming'")
+        return "hamming"
     if metric_params:
         raise NotImplementedError(
             "metric_params are not supported by the MI355X backend (Euclidean metric only)")
@@ -122,7 +128,10 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
             raise ValueError(
                 "weights not recognized: should be 'uniform', 'distance', or a callable function")
         self.effective_metric_ = _effective_metric(self.metric, self.p, self.metric_params)
-        self.effective_metric_params_ = {}
+        self.effective_metric_params_ = dict(self.metric_params or {}) if self.effective_metric_ == "hamming" else {}
+        if self.effective_metric_ == "hamming" and self.algorithm not in ("auto", "brute"):
+            raise ValueError(f"Metric 'hamming' not valid. Use sorted(sklearn.neighbors.VALID_METRICS['{self.algorithm}']) "
+                             "to get valid options. Metric can also be a callable function.")
 
     def fit(self, X, y):
         """Store the reference rows and targets in HBM and compute the independent
@@ -137,7 +146,14 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
         self._y = y
         self._fit_X = X
         self.n_samples_fit_ = X.shape[0]
-        self._fit_method = _resolve_fit_method(self.algorithm, X.shape[0], X.shape[1], self.n_neighbors)
+        self._fit_method = ("brute" if self.effective_metric_ == "hamming" else
+                            _resolve_fit_method(self.algorithm, X.shape[0], X.shape[1], self.n_neighbors))
+        if self.effective_metric_ == "hamming":
+            w = self.effective_metric_params_.get("w")
+            w = np.ones(X.shape[1]) if w is None else np.asarray(w, dtype=np.float64).reshape(-1)
+            if w.size != X.shape[1]:
+                raise ValueError(f"the Hamming weights have {w.size} entries for {X.shape[1]} columns")
+            self._hamming_w = w
         self._affine = affine
         self._device = default_device() if device is None else device
         self._build_engine()
@@ -147,6 +163,8 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
     def _build_engine(self):
         y2 = self._y.reshape(-1, 1) if self._y.ndim == 1 else self._y
         self._engine = KNNEngine(self._fit_X, np.asarray(y2, dtype=np.float64), device=self._device)
+        if getattr(self, "effective_metric_", "euclidean") == "hamming":
+            self._engine.set_hamming_weights(self._hamming_w)
         if self._affine is not None:
             d_in, center, scale, proj = self._affine
             self._engine.set_affine(d_in, center, scale, proj)
@@ -165,6 +183,8 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
         return state
 
     def _formula(self) -> str:
+        if getattr(self, "effective_metric_", "euclidean") == "hamming":
+            return "hamming"
         return "direct" if self._fit_method == "kd_tree" else "expanded"
 
     def _set_independent_prediction_attributes(self, y) -> None:
@@ -406,11 +426,19 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
         validate_data(self, X=X, y=y, ensure_all_finite=True, multi_output=True)
         self._set_fitted_transformer(X, y)
 
-        center, scale, proj = self.transformer_.affine_params()
-        X_arr = np.ascontiguousarray(
-            validate_data(self.transformer_, X=X, reset=False, dtype=np.float64), dtype=np.float64)
         device = default_device()
-        X_transformed = _native.affine_transform_host(X_arr, center, scale, proj, device=device)
+        # Affine feature spaces are applied on the device (fit rows here, query rows inside the launch);
+        # tree-node spaces (scikit-learn forests) are evaluated on the host and the device searches node ids.
+        self._device_affine = hasattr(self.transformer_, "affine_params")
+        if self._device_affine:
+            center, scale, proj = self.transformer_.affine_params()
+            X_arr = np.ascontiguousarray(
+                validate_data(self.transformer_, X=X, reset=False, dtype=np.float64), dtype=np.float64)
+            X_transformed = _native.affine_transform_host(X_arr, center, scale, proj, device=device)
+            affine = (X_arr.shape[1], center, scale, proj)
+        else:
+            X_transformed = self.transformer_.transform(X)
+            affine = None
 
         kwargs = {
             "n_neighbors": self.n_neighbors, "weights": self.weights, "algorithm": self.algorithm,
@@ -419,8 +447,7 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
         }
         kwargs.update(self._get_additional_regressor_init_kwargs())
         self.regressor_ = RawKNNRegressor(**kwargs)
-        self.regressor_._fit_arrays(X_transformed, y, affine=(X_arr.shape[1], center, scale, proj),
-                                    device=device)
+        self.regressor_._fit_arrays(X_transformed, y, affine=affine, device=device)
         self.regressor_._set_dataframe_index_in(X)
 
         self.n_features_in_ = self.regressor_.n_features_in_
@@ -432,8 +459,12 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
 
     def _validate_raw_query(self, X):
         """Same checks the transformer's ``transform`` applies (feature names/count, finiteness)
-        without transforming on the host."""
+        without transforming on the host -- or, for host-side feature spaces, the transform itself."""
         check_is_fitted(self, "transformer_")
+        if not getattr(self, "_device_affine", True):
+            if is_torch_cuda_tensor(X):
+                X = X.cpu().numpy()
+            return np.ascontiguousarray(self.transformer_.transform(X), dtype=np.float64)
         if is_torch_cuda_tensor(X):
             d_in = self.regressor_.engine_.d_in
             if X.ndim != 2 or X.shape[1] != d_in:
@@ -452,7 +483,7 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
         k = reg._resolve_k(n_neighbors)
         if X is not None:
             X = self._validate_raw_query(X)
-        dist, idx = reg._kneighbors_engine(X, k, apply_affine=X is not None,
+        dist, idx = reg._kneighbors_engine(X, k, apply_affine=X is not None and self._device_affine,
                                            use_deterministic_ordering=use_deterministic_ordering,
                                            owner=self.transformer_)
         return reg._finish_kneighbors(dist, idx, return_distance, return_dataframe_index)
@@ -463,7 +494,8 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
         check_is_fitted(self, "regressor_")
         if X is not None:
             X = self._validate_raw_query(X)
-        return self.regressor_._predict_engine(X, apply_affine=X is not None, owner=self.transformer_)
+        return self.regressor_._predict_engine(X, apply_affine=X is not None and self._device_affine,
+                                               owner=self.transformer_)
 
     def kneighbors_chunks(self, tiles, n_neighbors=None, return_distance=True, return_dataframe_index=False,
                           use_deterministic_ordering=True, out=None):
@@ -473,7 +505,7 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
         reg = self.regressor_
         k = reg._resolve_k(n_neighbors)
         o = None if out is None else (out[0], out[1], None)
-        dist, idx, _ = reg._stream_tiles(tiles, self._validate_raw_query, k, apply_affine=True, weights=None,
+        dist, idx, _ = reg._stream_tiles(tiles, self._validate_raw_query, k, apply_affine=self._device_affine, weights=None,
                                          return_distance=return_distance,
                                          use_deterministic_ordering=use_deterministic_ordering, out=o,
                                          owner=self.transformer_)
@@ -482,8 +514,8 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
     def predict_chunks(self, tiles, out=None):
         """``predict`` over an iterable of untransformed host tiles as one streamed call."""
         check_is_fitted(self, "regressor_")
-        return self.regressor_._predict_chunks(tiles, self._validate_raw_query, apply_affine=True, out=out,
-                                               owner=self.transformer_)
+        return self.regressor_._predict_chunks(tiles, self._validate_raw_query, apply_affine=self._device_affine,
+                                               out=out, owner=self.transformer_)
 
     def score(self, X, y):
         """REF _base.py:350-352."""

@@ -75,6 +75,10 @@ class KNNEngine:
         self.d_in = int(d_in)
         self.has_affine = True
 
+    def set_hamming_weights(self, w):
+        """Per-column weights of the weighted-Hamming search over tree node ids (``formula="hamming"``)."""
+        self._index.set_hamming_weights(w)
+
     def stats(self) -> dict:
         return self._index.stats()
 
@@ -86,7 +90,8 @@ class KNNEngine:
               weight_mode=_native.WEIGHTS_UNIFORM, row_offset=0, check_finite=False):
         return self._index.make_opts(
             k, exclude_self=exclude_self, deterministic=deterministic, decimals=decimals,
-            formula=_native.FORMULA_DIRECT if formula == "direct" else _native.FORMULA_EXPANDED,
+            formula={"direct": _native.FORMULA_DIRECT, "hamming": _native.FORMULA_HAMMING}.get(
+                formula, _native.FORMULA_EXPANDED),
             apply_affine=apply_affine, weight_mode=weight_mode, row_offset=row_offset,
             check_finite=check_finite)
 

@@ -1,0 +1,147 @@
+"""RFNN / GBNN: nearest neighbours by tree-node co-occurrence.
+
+    WeightedTreesNNRegressor   /root/reference/src/sknnr/_weighted_trees.py:17-140
+    RFNNRegressor              /root/reference/src/sknnr/_rfnn.py:16-239
+    GBNNRegressor              /root/reference/src/sknnr/_gbnn.py:16-249
+
+A forest per target is grown on the host by scikit-learn (``RFNodeTransformer`` /
+``GBNodeTransformer``); a sample's features are the nodes it reaches, the distance between two samples
+is the weighted share of trees in which they reach different nodes.  That weighted-Hamming search and
+everything after it (self exclusion, reorder, crosswalk, weighted mean) run on the GPU
+(``SKNNR_FORMULA_HAMMING``); the reference sends it through scikit-learn's slow generic path
+(``pairwise_distances_chunked`` + scipy ``cdist``) because ``hamming`` is excluded from ArgKmin.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from ._base import TransformedKNeighborsRegressor, YFitMixin
+from .transformers import GBNodeTransformer, RFNodeTransformer
+
+__all__ = ["WeightedTreesNNRegressor", "RFNNRegressor", "GBNNRegressor"]
+
+
+class WeightedTreesNNRegressor(YFitMixin, TransformedKNeighborsRegressor):
+    """Base of the tree-node regressors: brute-force search under the Hamming metric with one weight per
+    tree = the transformer's tree weight x the forest's weight / trees per boosting iteration."""
+
+    def __init__(self, *, n_neighbors=5, weights="uniform", n_jobs=None):
+        super().__init__(n_neighbors=n_neighbors, weights=weights, algorithm="brute", metric="hamming",
+                         n_jobs=n_jobs)
+
+    def _set_fitted_transformer(self, X, y) -> None:
+        super()._set_fitted_transformer(X, y)
+        self.hamming_weights_ = self._get_hamming_weights()
+
+    def _forest_weight_vector(self) -> np.ndarray:
+        n = self.transformer_.n_forests_
+        given = self.forest_weights
+        if isinstance(given, str) and given == "uniform":
+            return np.full(n, 1.0 / n, dtype=np.float64)
+        try:
+            fw = np.asarray(given, dtype=np.float64)
+        except (TypeError, ValueError) as err:
+            raise ValueError(f"`forest_weights` must be a sequence of numeric values, but got {given} instead.") from err
+        if fw.shape != (n,):
+            raise ValueError(f"Expected `forest_weights` to have length {n}, but got {fw.size}.")
+        if not np.all(np.isfinite(fw)):
+            raise ValueError(f"Expected elements in `forest_weights` to be finite, but got {fw}.")
+        if np.any(fw < 0):
+            raise ValueError(f"Expected elements in `forest_weights` to be non-negative, but got {fw}.")
+        if np.sum(fw) <= 0:
+            raise ValueError(f"At least one element in `forest_weights` must be positive, but got {fw}.")
+        return fw / np.sum(fw)
+
+    def _get_hamming_weights(self) -> np.ndarray:
+        """One weight per tree; they sum to 1 over all forests (REF _weighted_trees.py:65-98)."""
+        fw = self._forest_weight_vector()
+        per_forest = [tw * (f / per_iter) for tw, f, per_iter in
+                      zip(self.transformer_.tree_weights_, fw, self.transformer_.n_trees_per_iteration_)]
+        return np.hstack(per_forest)
+
+    def _get_additional_regressor_init_kwargs(self) -> dict:
+        return {"metric_params": {"w": self.hamming_weights_}}
+
+
+class RFNNRegressor(WeightedTreesNNRegressor):
+    """Random-forest nearest neighbours (Crookston & Finley 2008): one random forest per target
+    (``y_fit`` if given, else ``y``), neighbours by node co-occurrence.  Parameters as in the reference
+    (forest parameters are passed to ``RFNodeTransformer``; ``_reg`` / ``_clf`` suffixes pick the
+    regressor / classifier variant)."""
+
+    def __init__(self, *, n_estimators=50, criterion_reg="squared_error", criterion_clf="gini", max_depth=None,
+                 min_samples_split=2, min_samples_leaf=5, min_weight_fraction_leaf=0.0, max_features_reg=1.0,
+                 max_features_clf="sqrt", max_leaf_nodes=None, min_impurity_decrease=0.0, bootstrap=True,
+                 oob_score=False, n_jobs=None, random_state=None, verbose=0, warm_start=False,
+                 class_weight_clf=None, ccp_alpha=0.0, max_samples=None, monotonic_cst=None,
+                 forest_weights="uniform", n_neighbors=5, weights="uniform"):
+        self.n_estimators = n_estimators
+        self.criterion_reg = criterion_reg
+        self.criterion_clf = criterion_clf
+        self.max_depth = max_depth
+        self.min_samples_split = min_samples_split
+        self.min_samples_leaf = min_samples_leaf
+        self.min_weight_fraction_leaf = min_weight_fraction_leaf
+        self.max_features_reg = max_features_reg
+        self.max_features_clf = max_features_clf
+        self.max_leaf_nodes = max_leaf_nodes
+        self.min_impurity_decrease = min_impurity_decrease
+        self.bootstrap = bootstrap
+        self.oob_score = oob_score
+        self.n_jobs = n_jobs
+        self.random_state = random_state
+        self.verbose = verbose
+        self.warm_start = warm_start
+        self.class_weight_clf = class_weight_clf
+        self.ccp_alpha = ccp_alpha
+        self.max_samples = max_samples
+        self.monotonic_cst = monotonic_cst
+        self.forest_weights = forest_weights
+        super().__init__(n_neighbors=n_neighbors, weights=weights, n_jobs=self.n_jobs)
+
+    def _get_transformer(self):
+        names = RFNodeTransformer._get_param_names()
+        return RFNodeTransformer(**{name: getattr(self, name) for name in names})
+
+
+class GBNNRegressor(WeightedTreesNNRegressor):
+    """Gradient-boosting nearest neighbours: one boosted ensemble per target, trees weighted by their
+    stage's training improvement (or uniformly).  Parameters as in the reference."""
+
+    def __init__(self, *, loss_reg="squared_error", loss_clf="log_loss", learning_rate=0.1, n_estimators=100,
+                 subsample=1.0, criterion="friedman_mse", min_samples_split=2, min_samples_leaf=1,
+                 min_weight_fraction_leaf=0.0, max_depth=3, min_impurity_decrease=0.0, init=None,
+                 random_state=None, max_features=None, alpha_reg=0.9, verbose=0, max_leaf_nodes=None,
+                 warm_start=False, validation_fraction=0.1, n_iter_no_change=None, tol=0.0001, ccp_alpha=0.0,
+                 forest_weights="uniform", tree_weighting_method="train_improvement", n_neighbors=5,
+                 weights="uniform", n_jobs=None):
+        self.loss_reg = loss_reg
+        self.loss_clf = loss_clf
+        self.learning_rate = learning_rate
+        self.n_estimators = n_estimators
+        self.subsample = subsample
+        self.criterion = criterion
+        self.min_samples_split = min_samples_split
+        self.min_samples_leaf = min_samples_leaf
+        self.min_weight_fraction_leaf = min_weight_fraction_leaf
+        self.max_depth = max_depth
+        self.min_impurity_decrease = min_impurity_decrease
+        self.init = init
+        self.random_state = random_state
+        self.max_features = max_features
+        self.alpha_reg = alpha_reg
+        self.verbose = verbose
+        self.max_leaf_nodes = max_leaf_nodes
+        self.warm_start = warm_start
+        self.validation_fraction = validation_fraction
+        self.n_iter_no_change = n_iter_no_change
+        self.tol = tol
+        self.ccp_alpha = ccp_alpha
+        self.forest_weights = forest_weights
+        self.tree_weighting_method = tree_weighting_method
+        super().__init__(n_neighbors=n_neighbors, weights=weights, n_jobs=n_jobs)
+
+    def _get_transformer(self):
+        names = GBNodeTransformer._get_param_names()
+        return GBNodeTransformer(**{name: getattr(self, name) for name in names})

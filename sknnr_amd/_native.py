@@ -19,6 +19,7 @@ MEM_HOST = 0
 MEM_DEVICE = 1
 FORMULA_EXPANDED = 0
 FORMULA_DIRECT = 1
+FORMULA_HAMMING = 2
 WEIGHTS_UNIFORM = 0
 WEIGHTS_DISTANCE = 1
 WEIGHTS_EXPLICIT = 2
@@ -40,6 +41,7 @@ EXPORTED_SYMBOLS = (
     "sknnr_index_create",
     "sknnr_index_destroy",
     "sknnr_index_set_affine",
+    "sknnr_index_set_hamming_weights",
     "sknnr_affine_transform",
     "sknnr_index_shape",
     "sknnr_get_stats",
@@ -138,6 +140,7 @@ def load(build_if_missing: bool = False):
     lib.sknnr_index_destroy.argtypes = [vp]
     lib.sknnr_index_destroy.restype = None
     lib.sknnr_index_set_affine.argtypes = [vp, c_int32, vp, vp, vp]
+    lib.sknnr_index_set_hamming_weights.argtypes = [vp, vp, c_int32]
     lib.sknnr_affine_transform.argtypes = [vp, c_int64, c_int32, vp, vp, vp, c_int32, vp, c_int32]
     lib.sknnr_index_shape.argtypes = [vp, POINTER(c_int64), POINTER(c_int32), POINTER(c_int32),
                                       POINTER(c_int32), POINTER(c_int32)]
@@ -224,6 +227,10 @@ class Index:
         check(load().sknnr_index_set_affine(self.handle, d_in, _host_ptr(center), _host_ptr(scale),
                                             _host_ptr(proj)))
         self.d_in = d_in
+
+    def set_hamming_weights(self, w):
+        w = _c_f64(w).reshape(-1)
+        check(load().sknnr_index_set_hamming_weights(self.handle, _host_ptr(w), w.size))
 
     def stats(self) -> dict:
         st = Stats()

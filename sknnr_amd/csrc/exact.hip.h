@@ -333,6 +333,8 @@ struct SelectArgs {
     int pow10_is_divisor;  // decimals < 0
     double pow10;          // 10^|decimals|
     long row_offset;       // global row of query 0 of this launch
+    const double* hw;      // formula 2 (weighted Hamming): (d) weights
+    double hw_sum;         // ... and their sum in index order (what scipy divides by)
     double* out_dist;      // (nq, k) or null
     long* out_idx;         // (nq, k)
 };
@@ -661,9 +663,9 @@ __device__ __forceinline__ void heap_push_ref(double* hv, int* hi, int k, double
     hi[cur] = id;
 }
 
-// formula 1 (the kd_tree stand-in): rows ordered by (d2, index), as oracle_argkmin_direct keeps
-// them -- a sorted list; a value equal to the current k-th is not admitted, equal values stay in
-// index order.  Unfilled slots hold DBL_MAX.
+// formula 1 (the kd_tree stand-in) and formula 2 (weighted Hamming): rows ordered by (d2, index), as
+// oracle_argkmin_direct keeps them -- a sorted list; a value equal to the current k-th is not admitted,
+// equal values stay in index order.  Unfilled slots hold DBL_MAX.
 __device__ __forceinline__ void sorted_insert_ref(double* hv, int* hi, int k, double v, int id) {
     // caller has checked v < hv[k-1]
     int pos = k - 1;
@@ -732,6 +734,7 @@ constexpr int kScanWaves = 4;
 constexpr int kScanQPW = 2;                          // queries whose heaps one wave replays
 constexpr int kScanNQ = kScanWaves * kScanQPW;       // queries per workgroup pass
 constexpr int kScanRefs = 2 * kScanWaves * 64;       // references per step: two per thread
+constexpr int kScanColChunk = 1024;                  // feature columns of the queries held in LDS at a time
 
 // Workgroup LDS: xs[NQ][dpad] | qn[NQ] | hv[NQ][KK] | hi[NQ][kkp] | stack[NQ][stk] | d2[NQ][kScanRefs]
 struct ScanLayout {
@@ -740,7 +743,7 @@ struct ScanLayout {
 };
 __host__ __device__ inline ScanLayout scan_layout(int d, int kk) {
     ScanLayout L;
-    L.dpad = (d + 1) & ~1;
+    L.dpad = ((d < kScanColChunk ? d : kScanColChunk) + 1) & ~1;
     L.kkp = kk + (kk & 1);
     L.stk = (2 * kk + 4 + 1) & ~1;
     size_t b = 0;
@@ -786,12 +789,19 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
         const int n_here = (int)((n_items - f0) < NQ ? (n_items - f0) : NQ);
         __syncthreads();  // previous pass's LDS state is dead
         // padding slots repeat the pass's last query; nothing is written for them
-        for (int e = tid; e < NQ * d; e += NT) {
-            const int qi = e / d, c = e - qi * d;
-            const long fi = f0 + (qi < n_here ? qi : n_here - 1);
-            const long q = a.list ? (long)a.list[fi] : fi;
-            xs[qi * L.dpad + c] = s.xq[q * d + c];
-        }
+        // query rows of the pass, columns [c0, c0 + kScanColChunk): everything when d fits one chunk (the common
+        // case: loaded once per pass), else chunk by chunk inside the sweep (wide node-id matrices of RFNN / GBNN)
+        const bool chunked = d > kScanColChunk;
+        auto load_chunk = [&](int c0) {
+            const int cw = (d - c0) < kScanColChunk ? (d - c0) : kScanColChunk;
+            for (int e = tid; e < NQ * cw; e += NT) {
+                const int qi = e / cw, c = e - qi * cw;
+                const long fi = f0 + (qi < n_here ? qi : n_here - 1);
+                const long q = a.list ? (long)a.list[fi] : fi;
+                xs[qi * L.dpad + c] = s.xq[q * d + c0 + c];
+            }
+        };
+        if (!chunked) load_chunk(0);
         for (int i = tid; i < NQ * KK; i += NT) {
             const int qi = i / KK, e = i - qi * KK;
             hv_all[qi * KK + e] = DBL_MAX;
@@ -799,8 +809,10 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
         }
         __syncthreads();
         if (FORMULA == 0 && tid < NQ) {
+            const long fi = f0 + (tid < n_here ? tid : n_here - 1);
+            const double* xr = s.xq + (a.list ? (long)a.list[fi] : fi) * d;
             double qn = 0.0;
-            for (int c = 0; c < d; ++c) qn = fma(xs[tid * L.dpad + c], xs[tid * L.dpad + c], qn);
+            for (int c = 0; c < d; ++c) qn = fma(xr[c], xr[c], qn);
             qns[tid] = qn;
         }
         double root[kScanQPW];
@@ -815,8 +827,15 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
             double acc[NQ][2];
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) acc[qi][0] = acc[qi][1] = 0.0;
-            int c = 0;
-            for (; c + 8 <= d; c += 8) {
+            for (int c0 = 0; c0 < d; c0 += kScanColChunk) {
+            if (chunked) {
+                __syncthreads();  // everyone is done with the previous chunk
+                load_chunk(c0);
+                __syncthreads();
+            }
+            const int ce = (d - c0) < kScanColChunk ? d : c0 + kScanColChunk;
+            int c = c0;
+            for (; c + 8 <= ce; c += 8) {
                 double ra[8], rb[8];
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
@@ -827,10 +846,16 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
                 for (int qi = 0; qi < NQ; ++qi) {
 #pragma unroll
                     for (int w = 0; w < 8; ++w) {
-                        const double x = xs[qi * L.dpad + c + w];
+                        const double x = xs[qi * L.dpad + (c - c0) + w];
                         if (FORMULA == 0) {
                             acc[qi][0] = fma(x, ra[w], acc[qi][0]);
                             acc[qi][1] = fma(x, rb[w], acc[qi][1]);
+                        } else if (FORMULA == 2) {
+                            // weighted Hamming as scipy's cdist evaluates it on the float64 node ids:
+                            // s += (u != v) * w, in tree order  (REF _weighted_trees.py:53-59, :139-140)
+                            const double wv = s.hw[c + w];
+                            acc[qi][0] = x != ra[w] ? acc[qi][0] + wv : acc[qi][0];
+                            acc[qi][1] = x != rb[w] ? acc[qi][1] + wv : acc[qi][1];
                         } else {
                             const double ta = x - ra[w], tb = x - rb[w];
                             acc[qi][0] = acc[qi][0] + ta * ta;
@@ -839,14 +864,18 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
                     }
                 }
             }
-            for (; c < d; ++c) {
+            for (; c < ce; ++c) {
                 const double rav = cola[(size_t)c * ld], rbv = colb[(size_t)c * ld];
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) {
-                    const double x = xs[qi * L.dpad + c];
+                    const double x = xs[qi * L.dpad + (c - c0)];
                     if (FORMULA == 0) {
                         acc[qi][0] = fma(x, rav, acc[qi][0]);
                         acc[qi][1] = fma(x, rbv, acc[qi][1]);
+                    } else if (FORMULA == 2) {
+                        const double wv = s.hw[c];
+                        acc[qi][0] = x != rav ? acc[qi][0] + wv : acc[qi][0];
+                        acc[qi][1] = x != rbv ? acc[qi][1] + wv : acc[qi][1];
                     } else {
                         const double ta = x - rav, tb = x - rbv;
                         acc[qi][0] = acc[qi][0] + ta * ta;
@@ -854,6 +883,7 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
                     }
                 }
             }
+            }  // column chunks
             const double rna = (FORMULA == 0 && ja < s.n_ref) ? s.rn[ja] : 0.0;
             const double rnb = (FORMULA == 0 && jb < s.n_ref) ? s.rn[jb] : 0.0;
             __syncthreads();  // the previous step's replay has finished reading d2buf (and qns is published)
@@ -866,6 +896,10 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
                     db = qn + (-2.0 * db) + rnb;
                     da = da > 0.0 ? da : 0.0;
                     db = db > 0.0 ? db : 0.0;
+                }
+                if (FORMULA == 2) {
+                    da = da / s.hw_sum;
+                    db = db / s.hw_sum;
                 }
                 d2buf[qi * kScanRefs + tid] = ja < s.n_ref ? da : INFINITY;
                 d2buf[qi * kScanRefs + NT + tid] = jb < s.n_ref ? db : INFINITY;
@@ -920,7 +954,7 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
                 int n = 0;
                 for (int e = 0; e < KK; ++e) {
                     if (e == drop) continue;
-                    hv[n] = sqrt(hv[e] > 0.0 ? hv[e] : 0.0);
+                    hv[n] = FORMULA == 2 ? hv[e] : sqrt(hv[e] > 0.0 ? hv[e] : 0.0);  // (a Hamming distance is not a square)
                     hi[n] = hi[e];
                     ++n;
                 }

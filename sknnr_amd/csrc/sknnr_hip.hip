@@ -167,6 +167,9 @@ struct sknnr_index {
     DevBuf<double> center, scale, proj;  // proj padded to (d_in, 16*ks) when ks > 0 else (d_in, d)
     bool has_center = false, has_scale = false, has_proj = false;
 
+    DevBuf<double> hw;       // weighted-Hamming weights (one per column), set by sknnr_index_set_hamming_weights
+    double hw_sum = 0.0;
+    bool has_hw = false;
     DevBuf<double> ref64, refT, rn64, y64, mu_dev;  // refT: (d, n_ref) transposed copy for the exact scan
     DevBuf<char> rimg;
     DevBuf<char> rhi2, rlo2;  // coarse2_kernel's image: [hi | |r'|^2] records for the LDS stages, lo fragments apart
@@ -637,6 +640,25 @@ extern "C" int sknnr_index_set_affine(sknnr_index* ix, int32_t d_in, const doubl
     return SKNNR_OK;
 }
 
+extern "C" int sknnr_index_set_hamming_weights(sknnr_index* ix, const double* w, int32_t n) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    if (!w || n != ix->d) return fail(SKNNR_ERR_INVALID, "w must hold one weight per column (%d), got %d", ix->d, n);
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (!(w[i] >= 0.0) || !(w[i] < std::numeric_limits<double>::infinity()))
+            return fail(SKNNR_ERR_INVALID, "Hamming weights must be finite and non-negative");
+        total += w[i];  // index order, as scipy's cdist accumulates it
+    }
+    if (!(total > 0.0)) return fail(SKNNR_ERR_INVALID, "Hamming weights must not sum to zero");
+    std::lock_guard<std::mutex> lock(ix->mtx);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(ix->hw.ensure(n));
+    HIP_TRY(hipMemcpy(ix->hw.p, w, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    ix->hw_sum = total;
+    ix->has_hw = true;
+    return SKNNR_OK;
+}
+
 extern "C" int sknnr_affine_transform(const double* x, int64_t n, int32_t d_in, const double* center,
                                       const double* scale, const double* proj, int32_t d, double* out,
                                       int32_t device) {
@@ -987,7 +1009,7 @@ int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int
     // one 4-wave workgroup per pass of kScanNQ queries; 4 workgroups per CU keep the float64 pipes busy
     const long passes = (max_items + kScanNQ - 1) / kScanNQ;
     const long blocks = std::max<long>(1, std::min<long>(passes, 256L * 4));
-    auto kern = s.formula == 0 ? exact_scan_kernel<0> : exact_scan_kernel<1>;
+    auto kern = s.formula == 0 ? exact_scan_kernel<0> : (s.formula == 1 ? exact_scan_kernel<1> : exact_scan_kernel<2>);
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     kern<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
     HIP_TRY(hipGetLastError());
@@ -1024,8 +1046,12 @@ int validate_call(sknnr_index* ix, const double* q, int64_t nq, const sknnr_quer
     }
     if (o->apply_affine && !ix->has_affine)
         return fail(SKNNR_ERR_INVALID, "apply_affine is set but no affine map was installed");
-    if (o->formula != SKNNR_FORMULA_EXPANDED && o->formula != SKNNR_FORMULA_DIRECT)
+    if (o->formula != SKNNR_FORMULA_EXPANDED && o->formula != SKNNR_FORMULA_DIRECT && o->formula != SKNNR_FORMULA_HAMMING)
         return fail(SKNNR_ERR_INVALID, "unknown formula %d", o->formula);
+    if (o->formula == SKNNR_FORMULA_HAMMING) {
+        if (!ix->has_hw) return fail(SKNNR_ERR_INVALID, "formula = HAMMING needs sknnr_index_set_hamming_weights first");
+        if (o->apply_affine) return fail(SKNNR_ERR_INVALID, "node ids are not mapped by an affine transform");
+    }
     if (o->n_neighbors + (o->exclude_self ? 1 : 0) > kScanMaxKK)
         return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d exceeds the HIP backend's limit of %d", o->n_neighbors,
                     kScanMaxKK - 1);
@@ -1039,7 +1065,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     const int kk = o->n_neighbors + (o->exclude_self ? 1 : 0);
     const bool affine = o->apply_affine != 0 && xdev != nullptr;
     const bool self_rows = xdev == nullptr;
-    const bool coarse = ix->ks > 0 && kk <= kCoarseMaxKK;
+    const bool coarse = ix->ks > 0 && kk <= kCoarseMaxKK && o->formula != SKNNR_FORMULA_HAMMING;
     const int d_x = affine ? ix->d_in : ix->d;
     if (nq > 0x7fffffffL) return fail(SKNNR_ERR_UNSUPPORTED, "more than 2^31 - 1 query rows in one call");
     if (affine && ix->ks == 0)
@@ -1082,6 +1108,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     call.pow10_is_divisor = o->decimals < 0;
     call.pow10 = std::pow(10.0, std::abs(o->decimals));
     call.row_offset = o->row_offset;
+    call.hw = ix->hw.p;
+    call.hw_sum = ix->hw_sum;
     call.out_dist = d_dist;
     call.out_idx = d_idx;
 

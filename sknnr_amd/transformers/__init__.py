@@ -7,7 +7,12 @@ from ._transformers import (
     StandardScalerWithDOF,
 )
 
+from ._tree_nodes import GBNodeTransformer, RFNodeTransformer, TreeNodeTransformer
+
 __all__ = [
+    "TreeNodeTransformer",
+    "RFNodeTransformer",
+    "GBNodeTransformer",
     "StandardScalerWithDOF",
     "MahalanobisTransformer",
     "CCATransformer",

@@ -78,3 +78,36 @@ def assert_neighbors_match(idx, dist, ref_idx, ref_dist, fit_X=None, rtol=1e-5, 
         if same_set and not same_row:
             raise AssertionError(f"row {r}: same neighbours in a different order: {idx[r]} vs {ref_idx[r]}")
     return int(bad.sum())
+
+
+def assert_hamming_neighbors_match(idx, dist, ref_idx, ref_dist, fit_ids, q_ids, w, row_offset_self=None,
+                                   rtol=1e-5, atol=1e-8):
+    """Weighted-Hamming results against the reference's: distances must agree (as sorted rows: bitwise
+    equal distances may be listed in either order of their rows); indices must agree except inside the
+    class of reference rows tied EXACTLY at the k-th distance -- numpy's argpartition picks among those
+    by the internals of its introselect, which is not restated ("Hamming ties").  Every
+    returned index must really be at its reported distance, and nothing strictly closer may be missing.
+    Returns the number of rows whose index sets differ (all of them boundary-tie rows)."""
+    from scipy.spatial.distance import cdist
+
+    idx, ref_idx = np.asarray(idx), np.asarray(ref_idx)
+    dist, ref_dist = np.asarray(dist), np.asarray(ref_dist)
+    np.testing.assert_allclose(np.sort(dist, axis=1), np.sort(ref_dist, axis=1), rtol=rtol, atol=atol)
+    full = cdist(np.asarray(q_ids, dtype=np.float64), np.asarray(fit_ids, dtype=np.float64), "hamming", w=w)
+    differing = 0
+    for r in range(idx.shape[0]):
+        np.testing.assert_allclose(full[r, idx[r]], dist[r], rtol=rtol, atol=atol)  # honest distances
+        if sorted(idx[r].tolist()) == sorted(ref_idx[r].tolist()):
+            continue
+        differing += 1
+        kth = ref_dist[r].max()
+        only_mine = set(idx[r].tolist()) - set(ref_idx[r].tolist())
+        only_ref = set(ref_idx[r].tolist()) - set(idx[r].tolist())
+        for j in only_mine | only_ref:
+            assert full[r, j] == pytest.approx(kth, rel=rtol, abs=atol), (
+                f"row {r}: index {j} at distance {full[r, j]} is not tied with the k-th distance {kth}")
+        row = full[r].copy()
+        if row_offset_self is not None:
+            row[row_offset_self + r] = np.inf
+        assert (np.sort(row)[: idx.shape[1]].max() <= kth + atol + rtol * abs(kth)), f"row {r}: a closer row is missing"
+    return differing

@@ -12,8 +12,8 @@ small ``.npz`` files.  Only arrays are written (data, fitted matrices, neighbour
 indices, distances, predictions, scores); no reference source travels.
 
 ``tests/golden/ref_regressions/*.npz`` are the reference's own regression data
-files for the in-scope estimators (raw, euclidean, mahalanobis, gnn, msn), copied
-verbatim from /root/reference/tests/test_regressions/.
+files (raw, euclidean, mahalanobis, gnn, msn, and -- since round 2 -- randomForest and gbnn),
+copied verbatim from /root/reference/tests/test_regressions/.
 """
 
 from __future__ import annotations
@@ -32,7 +32,9 @@ import sknnr  # noqa: E402  (the reference)
 from sklearn.model_selection import train_test_split  # noqa: E402
 from sknnr import (  # noqa: E402
     EuclideanKNNRegressor,
+    GBNNRegressor,
     GNNRegressor,
+    RFNNRegressor,
     MahalanobisKNNRegressor,
     MSNRegressor,
     RawKNNRegressor,
@@ -214,13 +216,88 @@ def synthetic_estimator_cases():
         print("synth_est", name, "D_t", est.n_features_in_, str(out["fit_method"]))
 
 
+def synthetic_wide_estimator_cases():
+    """The two BASELINE shapes the d = 16 fixtures above do not reach: GNN in 32 dimensions (C3) and
+    Mahalanobis in 64 (C4), at fixture size."""
+    cases = {
+        "gnn_d32": (GNNRegressor, dict(n_neighbors=7, weights="distance"), "positive", 32),
+        "mahalanobis_d64": (MahalanobisKNNRegressor, dict(n_neighbors=5), "linear", 64),
+    }
+    for name, (cls, kw, kind, d) in cases.items():
+        x_ref, y, x_q = synth.make_problem(2000, 512, d, t=40, kind=kind)  # 40 targets: CCA keeps all 32 axes
+        est = cls(**kw).fit(x_ref, y)
+        dist, nn = est.kneighbors(x_q)
+        out = dict(
+            dist=dist, nn=nn.astype(np.int32), pred=est.predict(x_q),
+            indep_score=np.asarray(est.independent_score_), indep_pred_rows=est.independent_prediction_[::8],
+            fit_method=np.asarray(est.regressor_._fit_method), n_features_in_=np.asarray(est.n_features_in_),
+            **transformer_params(est),
+        )
+        np.savez_compressed(os.path.join(HERE, f"synth_est_{name}.npz"), **out)
+        print("synth_est", name, "D_t", est.n_features_in_, str(out["fit_method"]))
+
+
+def tree_cases():
+    """RFNN / GBNN on the Moscow data (the reference's regression configuration: random_state=42,
+    k=5): node-id matrices, Hamming weights and every output of the hot path, so that the GPU search
+    can be checked on exactly the reference's inputs without growing forests on the GPU box, plus a
+    synthetic case with real-valued tree weights (GBNN, train_improvement) and more rows."""
+    X, y = load_moscow_stjoes(return_X_y=True, as_frame=True)
+    X_train, X_test, y_train, y_test = train_test_split(X, y, train_size=0.8, shuffle=False)
+    for name, cls, kw in (("rfnn", RFNNRegressor, dict(random_state=42)),
+                          ("gbnn", GBNNRegressor, dict(random_state=42)),
+                          ("rfnn_weighted", RFNNRegressor, dict(random_state=42, n_estimators=20,
+                                                                 forest_weights=np.arange(1, y.shape[1] + 1))),
+                          ("gbnn_uniform", GBNNRegressor, dict(random_state=42, n_estimators=30,
+                                                               tree_weighting_method="uniform"))):
+        out = {}
+        for k in (1, 5):
+            est = cls(n_neighbors=k, **kw).fit(X_train, y_train)
+            if k == 5:
+                out["ids_train"] = est.transformer_.transform(X_train)
+                out["ids_test"] = est.transformer_.transform(X_test)
+                out["hamming_weights"] = est.hamming_weights_
+                out["indep_pred_uniform"] = est.independent_prediction_
+                out["indep_score_uniform"] = np.asarray(est.independent_score_)
+                out["pred_tgt_uniform"] = est.predict(X_test)
+                d, i = est.kneighbors(X_test, use_deterministic_ordering=False)
+                out["kn_tgt_k5_nd_dist"], out["kn_tgt_k5_nd_nn"] = d, i
+            d, i = est.kneighbors()
+            out[f"kn_ref_k{k}_dist"], out[f"kn_ref_k{k}_nn"] = d, i
+            d, i = est.kneighbors(X_test)
+            out[f"kn_tgt_k{k}_dist"], out[f"kn_tgt_k{k}_nn"] = d, i
+            d, i = est.kneighbors(X_test, return_dataframe_index=True)
+            out[f"kn_tgt_k{k}_ids"] = i
+        est = cls(n_neighbors=5, weights=yaimpute_weights, **kw).fit(X_train, y_train)
+        out["indep_pred_yaimpute"] = est.independent_prediction_
+        out["pred_tgt_yaimpute"] = est.predict(X_test)
+        est = cls(n_neighbors=5, weights="distance", **kw).fit(X_train, y_train)
+        out["pred_tgt_distance"] = est.predict(X_test)
+        np.savez_compressed(os.path.join(HERE, f"moscow_{name}.npz"), **out)
+        print("moscow", name, out["ids_train"].shape, "weights", len(out["hamming_weights"]))
+    x_ref, yy, x_q = synth.make_problem(1200, 400, 8, t=3, kind="linear")
+    est = GBNNRegressor(n_neighbors=5, n_estimators=25, random_state=0).fit(x_ref, yy)
+    d, i = est.kneighbors(x_q)
+    dr, ir = est.kneighbors()
+    np.savez_compressed(os.path.join(HERE, "synth_gbnn.npz"), ids_ref=est.transformer_.transform(x_ref),
+                        ids_q=est.transformer_.transform(x_q), hamming_weights=est.hamming_weights_, y=yy,
+                        dist=d, nn=i.astype(np.int32), ref_dist=dr, ref_nn=ir.astype(np.int32), pred=est.predict(x_q))
+    print("synth_gbnn", est.transformer_.transform(x_ref).shape)
+
+
 def main():
+    if "--only-new" in sys.argv:  # round 2 additions only (the earlier files stay byte for byte)
+        synthetic_wide_estimator_cases()
+        tree_cases()
+        return
     dump_dataset("moscow_stjoes", load_moscow_stjoes())
     dump_dataset("swo_ecoplot", load_swo_ecoplot())
     moscow_cases()
     swo_case()
     synthetic_raw_cases()
     synthetic_estimator_cases()
+    synthetic_wide_estimator_cases()
+    tree_cases()
 
 
 if __name__ == "__main__":

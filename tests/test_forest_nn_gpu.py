@@ -1,0 +1,190 @@
+"""RFNN / GBNN on the GPU: the weighted-Hamming search (SKNNR_FORMULA_HAMMING) through the C ABI against
+the oracle (bit for bit: same arithmetic, same tie rule) and against the reference's vectors (tie
+classes at the k-th distance compared as classes), and the estimator classes end to end."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from conftest import assert_hamming_neighbors_match, load_golden, yaimpute_weights
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["rfnn", "gbnn", "rfnn_weighted", "gbnn_uniform"]
+
+
+@pytest.fixture(scope="module")
+def N():
+    from sknnr_amd import _native
+
+    assert _native.device_count() >= 1, "no MI355X visible: the HIP path cannot be tested"
+    return _native
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_hamming_search_equals_the_oracle(N, O, name, deterministic):
+    """Node ids and weights the reference produced (1,750 / 3,500 / 700 / 1,050 trees: the wide ones
+    exercise the column-chunked scan): indices and float64 distances bit-equal to the oracle, for
+    queries and for the X=None self query."""
+    g = load_golden(f"moscow_{name}.npz")
+    ids_tr, ids_te, w = g["ids_train"].astype(np.float64), g["ids_test"].astype(np.float64), g["hamming_weights"]
+    ix = N.Index(ids_tr)
+    ix.set_hamming_weights(w)
+    for k in (1, 5, 9):
+        o = ix.make_opts(k, formula=N.FORMULA_HAMMING, deterministic=deterministic)
+        dist, idx = ix.kneighbors_host(ids_te, o)
+        od, oi = O.kneighbors_hamming(ids_tr, ids_te, w, k, deterministic=deterministic)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+        o = ix.make_opts(k, formula=N.FORMULA_HAMMING, deterministic=deterministic, exclude_self=True)
+        dist, idx = ix.kneighbors_host(None, o, nq=len(ids_tr))
+        od, oi = O.kneighbors_hamming(ids_tr, None, w, k, deterministic=deterministic)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+    st = ix.stats()
+    assert st["exact_only_queries"] == st["queries"] and st["coarse_queries"] == 0
+    ix.close()
+
+
+def test_hamming_search_larger_random_problem(N, O):
+    """More rows than a scan pass, few distinct node ids (ties everywhere), real-valued weights, device
+    tensors in and out, and a narrow matrix (T = 12 <= 128: the index also holds an unused MFMA image)."""
+    import torch
+
+    rng = np.random.default_rng(8)
+    for t, levels in ((12, 3), (300, 5), (1100, 20)):
+        ref = rng.integers(0, levels, (3000, t)).astype(np.float64)
+        q = rng.integers(0, levels, (5000, t)).astype(np.float64)
+        w = rng.random(t) + 0.01
+        ix = N.Index(ref, rng.standard_normal((3000, 2)))
+        ix.set_hamming_weights(w)
+        o = ix.make_opts(4, formula=N.FORMULA_HAMMING, row_offset=7)
+        qd = torch.as_tensor(q, device="cuda")
+        dd = torch.empty((5000, 4), dtype=torch.float64, device="cuda")
+        di = torch.empty((5000, 4), dtype=torch.int64, device="cuda")
+        ix.kneighbors_device(qd.data_ptr(), 5000, o, dd.data_ptr(), di.data_ptr())
+        torch.cuda.synchronize()
+        od, oi = O.kneighbors_hamming(ref, q, w, 4, row_offset=7)
+        np.testing.assert_array_equal(di.cpu().numpy(), oi)
+        np.testing.assert_array_equal(dd.cpu().numpy(), od)
+        ix.close()
+
+
+def test_hamming_errors(N):
+    ix = N.Index(np.zeros((10, 4)))
+    with pytest.raises(N.HipBackendError, match="set_hamming_weights"):
+        ix.kneighbors_host(np.zeros((2, 4)), ix.make_opts(1, formula=N.FORMULA_HAMMING))
+    with pytest.raises(N.HipBackendError, match="one weight per column"):
+        ix.set_hamming_weights(np.ones(3))
+    with pytest.raises(N.HipBackendError, match="finite and non-negative"):
+        ix.set_hamming_weights(np.array([1.0, -1.0, 1.0, 1.0]))
+    with pytest.raises(N.HipBackendError, match="sum to zero"):
+        ix.set_hamming_weights(np.zeros(4))
+    ix.close()
+
+
+@pytest.mark.parametrize("name, cls_name, kw", [
+    ("rfnn", "RFNNRegressor", dict(random_state=42)),
+    ("gbnn", "GBNNRegressor", dict(random_state=42)),
+    ("rfnn_weighted", "RFNNRegressor", dict(random_state=42, n_estimators=20, forest_weights=np.arange(1, 36))),
+    ("gbnn_uniform", "GBNNRegressor", dict(random_state=42, n_estimators=30, tree_weighting_method="uniform")),
+])
+def test_estimators_against_the_reference(name, cls_name, kw, moscow_frames):
+    """End to end (forests grown here by scikit-learn with the reference's seeds): Hamming weights equal,
+    neighbours and predictions as the reference's up to the tie classes at the k-th distance."""
+    import sknnr_amd
+
+    g = load_golden(f"moscow_{name}.npz")
+    f = moscow_frames
+    est = getattr(sknnr_amd, cls_name)(n_neighbors=5, **kw).fit(f["X_train"], f["y_train"])
+    np.testing.assert_array_equal(est.hamming_weights_, g["hamming_weights"])
+    assert est.hamming_weights_.sum() == pytest.approx(1.0)
+    assert est.n_features_in_ == g["ids_train"].shape[1]
+    ids_tr, ids_te, w = g["ids_train"], g["ids_test"], g["hamming_weights"]
+    d, i = est.kneighbors(f["X_test"])
+    n_tie_rows = assert_hamming_neighbors_match(i, d, g["kn_tgt_k5_nn"], g["kn_tgt_k5_dist"], ids_tr, ids_te, w)
+    d_ids, ids = est.kneighbors(f["X_test"], return_dataframe_index=True)
+    np.testing.assert_array_equal(ids, est.dataframe_index_in_[i])
+    d, i = est.kneighbors()
+    n_tie_rows += assert_hamming_neighbors_match(i, d, g["kn_ref_k5_nn"], g["kn_ref_k5_dist"], ids_tr, ids_tr, w,
+                                                 row_offset_self=0)
+    d1, i1 = est.kneighbors(f["X_test"], n_neighbors=1)
+    assert_hamming_neighbors_match(i1, d1, g["kn_tgt_k1_nn"], g["kn_tgt_k1_dist"], ids_tr, ids_te, w)
+    if n_tie_rows == 0:  # nothing tie-dependent: predictions and score must be the reference's
+        np.testing.assert_allclose(est.predict(f["X_test"]), g["pred_tgt_uniform"], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(est.independent_prediction_, g["indep_pred_uniform"], rtol=1e-5, atol=1e-8)
+        assert est.independent_score_ == pytest.approx(float(g["indep_score_uniform"]), rel=1e-6)
+        est_w = getattr(sknnr_amd, cls_name)(n_neighbors=5, weights=yaimpute_weights, **kw).fit(f["X_train"], f["y_train"])
+        np.testing.assert_allclose(est_w.predict(f["X_test"]), g["pred_tgt_yaimpute"], rtol=1e-5, atol=1e-8)
+
+
+def test_gbnn_on_synthetic_rows_matches_the_reference(N, O):
+    """The reference's GBNN on 1,200 x 8 synthetic rows (real-valued train-improvement weights): its
+    node ids / weights through the HIP search, its predictions from the HIP neighbours."""
+    g = load_golden("synth_gbnn.npz")
+    ref, q, w, y = g["ids_ref"].astype(np.float64), g["ids_q"].astype(np.float64), g["hamming_weights"], g["y"]
+    ix = N.Index(ref, y)
+    ix.set_hamming_weights(w)
+    dist, idx = ix.kneighbors_host(q, ix.make_opts(5, formula=N.FORMULA_HAMMING))
+    n_tie = assert_hamming_neighbors_match(idx, dist, g["nn"], g["dist"], ref, q, w)
+    pred = ix.predict_host(q, ix.make_opts(5, formula=N.FORMULA_HAMMING))
+    if n_tie == 0:
+        np.testing.assert_allclose(pred, g["pred"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(pred, O.predict(y, dist, idx, "uniform"), rtol=1e-12)
+    dist, idx = ix.kneighbors_host(None, ix.make_opts(5, formula=N.FORMULA_HAMMING, exclude_self=True), nq=len(ref))
+    assert_hamming_neighbors_match(idx, dist, g["ref_nn"], g["ref_dist"], ref, ref, w, row_offset_self=0)
+    ix.close()
+
+
+def test_forest_weight_validation(moscow_frames):
+    """REF _weighted_trees.py:100-136."""
+    import sknnr_amd
+
+    f = moscow_frames
+    y2 = f["y_train"].iloc[:, :2]
+    for bad, msg in (([1.0], "to have length 2"), (["a", "b"], "sequence of numeric"), ([1.0, np.inf], "to be finite"),
+                     ([1.0, -1.0], "non-negative"), ([0.0, 0.0], "must be positive")):
+        with pytest.raises(ValueError, match=msg):
+            sknnr_amd.RFNNRegressor(n_estimators=3, forest_weights=bad).fit(f["X_train"], y2)
+    est = sknnr_amd.RFNNRegressor(n_estimators=4, forest_weights=[3.0, 1.0], random_state=0).fit(f["X_train"], y2)
+    np.testing.assert_allclose(est.hamming_weights_, np.r_[np.full(4, 0.75 / 4), np.full(4, 0.25 / 4)])
+    # y_fit: forests grown on other targets than the ones predicted (REF _base.py:361-374)
+    est = sknnr_amd.GBNNRegressor(n_estimators=5, random_state=0).fit(f["X_train"], f["y_train"], y_fit=y2)
+    assert est.transformer_.n_forests_ == 2 and est.predict(f["X_test"]).shape == (33, f["y_train"].shape[1])
+    with pytest.raises(ValueError, match="Input X contains NaN"):
+        bad_x = f["X_test"].to_numpy().copy()
+        bad_x[0, 0] = np.nan
+        est.kneighbors(bad_x)
+
+
+@pytest.mark.parametrize("name", ["gnn_d32", "mahalanobis_d64"])
+def test_wide_synthetic_estimator_goldens(name):
+    """GNN in 32 dimensions (BASELINE C3's space) and Mahalanobis in 64 (C4's), fitted by the reference at
+    fixture size (the estimator fixtures were all d = 16)."""
+    import sknnr_amd
+    from conftest import assert_neighbors_match
+    from sknnr_amd import synth
+
+    g = load_golden(f"synth_est_{name}.npz")
+    cls, kw, kind, d = {"gnn_d32": (sknnr_amd.GNNRegressor, dict(n_neighbors=7, weights="distance"), "positive", 32),
+                        "mahalanobis_d64": (sknnr_amd.MahalanobisKNNRegressor, dict(n_neighbors=5), "linear", 64)}[name]
+    x_ref, y, x_q = synth.make_problem(2000, 512, d, t=40, kind=kind)
+    est = cls(**kw).fit(x_ref, y)
+    assert est.n_features_in_ == int(g["n_features_in_"]) == d
+    assert est.regressor_._fit_method == str(g["fit_method"])
+    dist, idx = est.kneighbors(x_q)
+    assert_neighbors_match(idx, dist, g["nn"], g["dist"])
+    np.testing.assert_allclose(est.predict(x_q), g["pred"], rtol=1e-5, atol=1e-8)
+    assert est.independent_score_ == pytest.approx(float(g["indep_score"]), rel=1e-6)
+    np.testing.assert_allclose(est.independent_prediction_[::8], g["indep_pred_rows"], rtol=1e-5, atol=1e-8)
+    st = est.regressor_.engine_.stats()
+    assert st["coarse_queries"] > 0 and st["exact_fallbacks"] < 0.02 * st["queries"], st

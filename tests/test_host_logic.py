@@ -119,7 +119,17 @@ def test_parameter_surface_matches_the_reference():
     assert set(E.MSNRegressor(n_components=3).get_params()) == set(raw) | {"n_components"}
     assert set(E.EuclideanKNNRegressor().get_params()) == set(raw)
     assert E.__all__ == ["RawKNNRegressor", "EuclideanKNNRegressor", "MahalanobisKNNRegressor",
-                         "MSNRegressor", "GNNRegressor"]
+                         "MSNRegressor", "GNNRegressor", "RFNNRegressor", "GBNNRegressor"]  # = REF src/sknnr/__init__.py
+    # REF _rfnn.py:154-186, _gbnn.py:158-192: keyword-only constructors, forest parameters + the three kNN ones
+    rf = E.RFNNRegressor().get_params()
+    assert rf["n_estimators"] == 50 and rf["min_samples_leaf"] == 5 and rf["forest_weights"] == "uniform"
+    assert {"criterion_reg", "criterion_clf", "max_features_reg", "max_features_clf", "class_weight_clf",
+            "n_neighbors", "weights", "n_jobs"} <= set(rf) and "metric" not in rf
+    gb = E.GBNNRegressor().get_params()
+    assert gb["n_estimators"] == 100 and gb["max_depth"] == 3 and gb["tree_weighting_method"] == "train_improvement"
+    assert {"loss_reg", "loss_clf", "alpha_reg", "forest_weights", "n_neighbors", "weights", "n_jobs"} <= set(gb)
+    with pytest.raises(TypeError):
+        E.RFNNRegressor(5)  # keyword-only, as in the reference
 
 
 def test_non_euclidean_metrics_raise():
@@ -127,8 +137,9 @@ def test_non_euclidean_metrics_raise():
 
     assert _effective_metric("minkowski", 2, None) == "euclidean"
     assert _effective_metric("euclidean", 2, None) == "euclidean"
+    assert _effective_metric("hamming", 2, {"w": [1.0]}) == "hamming"  # RFNN / GBNN (REF _weighted_trees.py:53-59)
     for bad in (("minkowski", 1, None), ("manhattan", 2, None), (lambda a, b: 0.0, 2, None),
-                ("minkowski", 2, {"w": [1.0]})):
+                ("minkowski", 2, {"w": [1.0]}), ("hamming", 2, {"V": 1})):
         with pytest.raises(NotImplementedError):
             _effective_metric(*bad)
 
