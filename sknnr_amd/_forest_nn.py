@@ -8,8 +8,8 @@ A forest per target is grown on the host by scikit-learn (``RFNodeTransformer`` 
 ``GBNodeTransformer``); a sample's features are the nodes it reaches, the distance between two samples
 is the weighted share of trees in which they reach different nodes.  That weighted-Hamming search and
 everything after it (self exclusion, reorder, crosswalk, weighted mean) run on the GPU
-(``SKNNR_FORMULA_HAMMING``); the reference sends it through scikit-learn's slow generic path
-(``pairwise_distances_chunked`` + scipy ``cdist``) because ``hamming`` is excluded from ArgKmin.
+(``SKNNR_FORMULA_HAMMING``); the reference sends it through scikit-learn's slow generic path (chunked
+pairwise distance matrices from scipy, then argpartition) because ``hamming`` is excluded from ArgKmin.
 """
 
 from __future__ import annotations
