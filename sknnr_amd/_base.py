@@ -525,9 +525,7 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
         return float(r2_score(y, pred))
 
     def __sklearn_tags__(self):
-        tags = super().__sklearn_tags__()
-        tags.estimator_type = "regressor"
-        tags.target_tags.multi_output = True
+        tags = super().__sklearn_tags__()  # (as REF _base.py:354-358: a plain BaseEstimator that rejects sparse input)
         tags.input_tags.sparse = False
         return tags
 

@@ -1,0 +1,125 @@
+"""The N > 1 path on real devices: two RCCL ranks (one process per GPU) run ShardedKNN over the HIP engine
+-- contiguous shards with uneven blocks, the chunk-cyclic in-place all-gather of bench.py, and the
+X=None self query -- and bench.py itself under torch.distributed.run.  Skipped when fewer than two
+MI355X are visible (the 1-GPU box): the driver's multi-GPU run must not be the first >1-rank RCCL run."""
+
+from __future__ import annotations
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _n_devices():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        import sknnr_amd
+        from sknnr_amd import synth
+        from sknnr_amd.distributed import ShardedKNN, cyclic_slot
+
+        x_ref, y, x_q = synth.make_problem(4000, 30001, 16, t=4, kind="positive", n_dup_queries=16)
+        x_q[1] = x_q[0]
+        est = sknnr_amd.GNNRegressor(n_neighbors=4, weights="distance").fit(x_ref, y)
+        sh = ShardedKNN(est)
+        xq_dev = torch.as_tensor(x_q, device="cuda")
+        d_all, i_all = sh.kneighbors(xq_dev, 4)                      # uneven contiguous shards
+        d_self, i_self = sh.kneighbors(None, 4)                      # sharded X=None
+        p_all = sh.predict(xq_dev)
+        n_loc, chunk = 12000, 5000                                    # chunk-cyclic, ragged last chunk
+        glob = xq_dev[: world * n_loc]
+        mine = torch.cat([glob[cyclic_slot(world, rank, a, min(n_loc, a + chunk)):
+                               cyclic_slot(world, rank, a, min(n_loc, a + chunk)) + min(n_loc, a + chunk) - a]
+                          for a in range(0, n_loc, chunk)])
+        d_cyc, i_cyc = sh.kneighbors_cyclic(mine, 4, chunk_rows=chunk)
+        a, b = sh.local_bounds(len(x_q))
+        d_pipe, i_pipe = sh.kneighbors_pipelined(xq_dev[a:b], len(x_q), 4, chunk_rows=7000)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), d_all=d_all.cpu().numpy(), i_all=i_all.cpu().numpy(),
+                 d_self=np.asarray(d_self), i_self=np.asarray(i_self), p_all=p_all.cpu().numpy(),
+                 d_cyc=d_cyc.cpu().numpy(), i_cyc=i_cyc.cpu().numpy(), d_pipe=d_pipe.cpu().numpy(),
+                 i_pipe=i_pipe.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rccl_ranks_match_the_single_call(tmp_path):
+    if _n_devices() < 2:
+        pytest.skip("needs two MI355X (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+
+    import sknnr_amd
+    from sknnr_amd import synth
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    x_ref, y, x_q = synth.make_problem(4000, 30001, 16, t=4, kind="positive", n_dup_queries=16)
+    x_q[1] = x_q[0]
+    est = sknnr_amd.GNNRegressor(n_neighbors=4, weights="distance").fit(x_ref, y)
+    d, i = est.kneighbors(x_q)
+    ds, is_ = est.kneighbors()
+    p = est.predict(x_q)
+    dg, ig = est.kneighbors(x_q[: world * 12000])
+    for rank in range(world):
+        r = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        for got, want in ((r["i_all"], i), (r["d_all"], d), (r["i_self"], is_), (r["d_self"], ds), (r["p_all"], p),
+                          (r["i_cyc"], ig), (r["d_cyc"], dg), (r["i_pipe"], i), (r["d_pipe"], d)):
+            np.testing.assert_array_equal(got, want)
+
+
+def test_bench_under_torch_distributed_run(tmp_path):
+    """bench.py --gpus 2 exactly as the driver launches it (small job): one JSON line, strong scaling by
+    default, roofline fraction <= 1 with the per-step kernel time summed over the gather chunks."""
+    if _n_devices() < 2:
+        pytest.skip("needs two MI355X")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--rows", "2000000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["total_rows"] == 2_000_000
+    assert 0 < res["roofline"]["frac"] <= 1.0 and res["roofline"]["timed_calls"] >= 2
+
+
+def test_bench_force_dist_single_rank():
+    """The N > 1 code path of bench.py (RCCL init, chunk-cyclic in-place all-gather on a side stream, summed
+    kernel timings) with one rank -- runs on the 1-GPU box."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1", "--rows", "3000000",
+           "--cpu-sample", "20000", "--no-extras"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["gather_in_place"] is True
+    assert res["roofline"]["timed_calls"] == 2 * 4  # four gather chunks per step, all summed
+    assert 0 < res["roofline"]["frac"] <= 1.0
+    assert res["parity_vs_cpu_reference"]["index_rows_equal"] == res["parity_vs_cpu_reference"]["rows"]
