@@ -1,4 +1,4 @@
-// coarse2.hip.h -- second-generation MFMA pre-filter for narrow feature spaces (KS <= 2, lists of 6 / 8).
+// coarse2.hip.h -- second-generation MFMA pre-filter for feature spaces up to 64 wide (KS <= 4, lists of 6 / 8).
 //
 // Same contract as coarse_kernel (coarse.hip.h): for every query, the M smallest ranking values
 //   v(q, r) ~= |r'|^2 - 2 q'.r'   seen by each of the two lanes that own the query, with the J-th
@@ -47,7 +47,9 @@ constexpr int kCoarse2Nqb = 2;
 constexpr int kQueueCap = 5;      // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
 constexpr int kQueueFlushAt = 3;  // a visit ends with a flush once some lane holds this many
 __host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb * kQueueCap * 64 * 8; }
-__host__ __device__ constexpr bool coarse2_supported(int ks, int m) { return ks <= 2 && (m == 6 || m == 8); }
+// measured against coarse_kernel on 4.19M x 50k rows (profiles/r02_v2_vs_v1.txt): 6-entry lists win for KS <= 4, 8-entry
+// lists for KS <= 3 (KS = 4 with 8-entry lists spills 88 bytes and loses)
+__host__ __device__ constexpr bool coarse2_supported(int ks, int m) { return (m == 6 && ks <= 4) || (m == 8 && ks <= 3); }
 
 // sum_j x[j] * y[j] over one 8-element fragment, f32 accumulate (v_dot2c_f32_f16)
 __device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc) {
@@ -96,27 +98,22 @@ __device__ __forceinline__ void step_test_only(const floatx16& x, float (&g)[5],
 template <int KS>
 __device__ __forceinline__ void tile_issue_and_test(floatx16& a, floatx16& c, const half8 (&ah)[KS], const half8 (&p)[KS],
                                                     const half8 (&q)[KS], float (&g)[5], float& m) {
-    static_assert(KS == 1 || KS == 2, "hand-scheduled for one or two K-steps");
-    if constexpr (KS == 2) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %[a], %[h0], %[p0], %[c]\n\t"
-                     "v_mfma_f32_32x32x16_f16 %[a], %[h1], %[p1], %[a]\n\t"
-                     "v_mfma_f32_32x32x16_f16 %[c], %[h0], %[q0], %[c]\n\t"
-                     "s_nop 3\n\t"  // (the third MFMA could only issue once the second had left the pipe)
-                     : [a] "=&v"(a), [c] "+v"(c)
-                     : [h0] "v"(ah[0]), [h1] "v"(ah[1]), [p0] "v"(p[0]), [p1] "v"(p[1]), [q0] "v"(q[0]));
-    } else {
-        asm volatile("v_mfma_f32_32x32x16_f16 %[a], %[h0], %[p0], %[c]\n\t"
-                     "v_mfma_f32_32x32x16_f16 %[c], %[h0], %[q0], %[c]\n\t"
-                     "s_nop 3\n\t"
-                     : [a] "=&v"(a), [c] "+v"(c)
-                     : [h0] "v"(ah[0]), [p0] "v"(p[0]), [q0] "v"(q[0]));
-    }
+    static_assert(KS >= 1 && KS <= 4, "hand-scheduled for one to four K-steps");
+    // first unit: KS MFMAs into `a` (C operand = |r'|^2 from `c`), then the first MFMA of the second unit
+    asm volatile("v_mfma_f32_32x32x16_f16 %[a], %[h0], %[p0], %[c]\n\t" : [a] "=&v"(a) : [c] "v"(c), [h0] "v"(ah[0]), [p0] "v"(p[0]));
+#pragma unroll
+    for (int s = 1; s < KS; ++s)
+        asm volatile("v_mfma_f32_32x32x16_f16 %[a], %[h], %[p], %[a]\n\t" : [a] "+v"(a) : [h] "v"(ah[s]), [p] "v"(p[s]));
+    asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[h0], %[q0], %[c]\n\t"
+                 "s_nop 3\n\t"  // (this MFMA could only issue once the last one of `a` had left the pipe)
+                 : [c] "+v"(c)
+                 : [h0] "v"(ah[0]), [q0] "v"(q[0]), "v"(a));
     const floatx16& x = a;
     asm volatile(SKNNR_TREE_A
                  : [g0] "=&v"(g[0]), [g1] "=&v"(g[1]), [g2] "=&v"(g[2]), [g3] "=&v"(g[3])
                  : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]),
                    [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]));
-    if constexpr (KS == 2)
+    if constexpr (KS >= 2)
         asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[h1], %[q1], %[c]\n\t" : [c] "+v"(c) : [h1] "v"(ah[1]), [q1] "v"(q[1]));
     asm volatile("v_min3_f32 %[g4], %[x12], %[x13], %[x14]\n\t"
                  "v_min3_f32 %[m], %[g0], %[g1], %[g2]\n\t"
@@ -126,6 +123,9 @@ __device__ __forceinline__ void tile_issue_and_test(floatx16& a, floatx16& c, co
                  : [g4] "=&v"(g[4]), [m] "=&v"(m)
                  : [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[15]), [g0] "v"(g[0]), [g1] "v"(g[1]),
                    [g2] "v"(g[2]), [g3] "v"(g[3]));
+#pragma unroll
+    for (int s = 2; s < KS; ++s)
+        asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[h], %[q], %[c]\n\t" : [c] "+v"(c) : [h] "v"(ah[s]), [q] "v"(q[s]));
 }
 
 template <int KS, int M>

@@ -558,7 +558,7 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
                 }
         }
         ix->ymax = std::sqrt(ymax2);
-        if (ks <= 2) {
+        if (ks <= 4) {
             // second-generation kernel: hi fragments + |r'|^2 per tile (staged through LDS), lo fragments in an
             // array of their own (read from L2 by the flush only)
             const int tps2 = tiles_per_stage2(ks);
@@ -941,6 +941,11 @@ int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t
     if (ix->ks == 1 && m_list == 8) return launch_coarse2_ks<1, 8>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 6) return launch_coarse2_ks<2, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 8) return launch_coarse2_ks<2, 8>(ix, nq_pad, kk, st);
+#ifndef SKNNR_DEV_ONLY_KS2_M6
+    if (ix->ks == 3 && m_list == 6) return launch_coarse2_ks<3, 6>(ix, nq_pad, kk, st);
+    if (ix->ks == 3 && m_list == 8) return launch_coarse2_ks<3, 8>(ix, nq_pad, kk, st);
+    if (ix->ks == 4 && m_list == 6) return launch_coarse2_ks<4, 6>(ix, nq_pad, kk, st);
+#endif
     return fail(SKNNR_ERR_UNSUPPORTED, "no second-generation coarse kernel for ks = %d, list length %d", ix->ks, m_list);
 }
 
