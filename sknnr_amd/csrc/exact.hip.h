@@ -765,7 +765,7 @@ __host__ __device__ inline size_t scan_block_bytes(int d, int kk) { return scan_
 // costs 1/8 of a sweep over the reference copy; the 8 x 512 values go to LDS and every wave then
 // offers them, in index order, to the heaps of its own two queries.  Each distance is the same
 // ascending-feature fma chain as before: results do not depend on the grouping.
-template <int FORMULA>
+template <int FORMULA, bool CHUNKED = false>
 __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = kScanWaves * 64;
@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
         // padding slots repeat the pass's last query; nothing is written for them
         // query rows of the pass, columns [c0, c0 + kScanColChunk): everything when d fits one chunk (the common
         // case: loaded once per pass), else chunk by chunk inside the sweep (wide node-id matrices of RFNN / GBNN)
-        const bool chunked = d > kScanColChunk;
+        constexpr bool chunked = CHUNKED;  // d > kScanColChunk (the launcher picks the instantiation)
         auto load_chunk = [&](int c0) {
             const int cw = (d - c0) < kScanColChunk ? (d - c0) : kScanColChunk;
             for (int e = tid; e < NQ * cw; e += NT) {
@@ -809,10 +809,14 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
         }
         __syncthreads();
         if (FORMULA == 0 && tid < NQ) {
-            const long fi = f0 + (tid < n_here ? tid : n_here - 1);
-            const double* xr = s.xq + (a.list ? (long)a.list[fi] : fi) * d;
             double qn = 0.0;
-            for (int c = 0; c < d; ++c) qn = fma(xr[c], xr[c], qn);
+            if (!chunked) {  // the rows are in LDS
+                for (int c = 0; c < d; ++c) qn = fma(xs[tid * L.dpad + c], xs[tid * L.dpad + c], qn);
+            } else {
+                const long fi = f0 + (tid < n_here ? tid : n_here - 1);
+                const double* xr = s.xq + (a.list ? (long)a.list[fi] : fi) * d;
+                for (int c = 0; c < d; ++c) qn = fma(xr[c], xr[c], qn);
+            }
             qns[tid] = qn;
         }
         double root[kScanQPW];
@@ -827,13 +831,13 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
             double acc[NQ][2];
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) acc[qi][0] = acc[qi][1] = 0.0;
-            for (int c0 = 0; c0 < d; c0 += kScanColChunk) {
+            for (int c0 = 0; c0 < (chunked ? d : 1); c0 += kScanColChunk) {
             if (chunked) {
                 __syncthreads();  // everyone is done with the previous chunk
                 load_chunk(c0);
                 __syncthreads();
             }
-            const int ce = (d - c0) < kScanColChunk ? d : c0 + kScanColChunk;
+            const int ce = (!chunked || (d - c0) < kScanColChunk) ? d : c0 + kScanColChunk;
             int c = c0;
             for (; c + 8 <= ce; c += 8) {
                 double ra[8], rb[8];

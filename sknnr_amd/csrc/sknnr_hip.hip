@@ -1014,7 +1014,10 @@ int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int
     // one 4-wave workgroup per pass of kScanNQ queries; 4 workgroups per CU keep the float64 pipes busy
     const long passes = (max_items + kScanNQ - 1) / kScanNQ;
     const long blocks = std::max<long>(1, std::min<long>(passes, 256L * 4));
-    auto kern = s.formula == 0 ? exact_scan_kernel<0> : (s.formula == 1 ? exact_scan_kernel<1> : exact_scan_kernel<2>);
+    const bool chunked = s.d > kScanColChunk;  // wide rows (tree node ids) are swept in column chunks
+    auto kern = s.formula == 0 ? (chunked ? exact_scan_kernel<0, true> : exact_scan_kernel<0, false>)
+              : s.formula == 1 ? (chunked ? exact_scan_kernel<1, true> : exact_scan_kernel<1, false>)
+                               : (chunked ? exact_scan_kernel<2, true> : exact_scan_kernel<2, false>);
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     kern<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
     HIP_TRY(hipGetLastError());
