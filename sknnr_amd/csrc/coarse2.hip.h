@@ -105,7 +105,10 @@ __device__ __forceinline__ void tile_issue_and_test(floatx16& a, floatx16& c, co
     for (int s = 1; s < KS; ++s)
         asm volatile("v_mfma_f32_32x32x16_f16 %[a], %[h], %[p], %[a]\n\t" : [a] "+v"(a) : [h] "v"(ah[s]), [p] "v"(p[s]));
     asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[h0], %[q0], %[c]\n\t"
-                 "s_nop 3\n\t"  // (this MFMA could only issue once the last one of `a` had left the pipe)
+                 // 11 wait states must separate the last MFMA of `a` from the first read of its result (8-pass
+                 // MFMA -> VALU read, guide section 5.7); counting the MFMA in between as ONE, twelve idle slots
+                 // make that certain whatever the issue timing (the wave is waiting for its MFMAs anyway)
+                 "s_nop 7\n\ts_nop 3\n\t"
                  : [c] "+v"(c)
                  : [h0] "v"(ah[0]), [q0] "v"(q[0]), "v"(a));
     const floatx16& x = a;
