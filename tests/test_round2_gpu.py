@@ -338,3 +338,41 @@ def test_stats_sum_the_calls_of_a_step(N):
     assert 0.5 * one["total_coarse_ms"] < four["total_coarse_ms"] < 3.0 * one["total_coarse_ms"]
     assert four["total_kernel_ms"] >= four["total_coarse_ms"]
     eng.close()
+
+
+def test_chunked_outputs_into_memmaps_and_callable_weights(N, tmp_path):
+    """The raster workflow of REF docs/pages/usage.md:101-128 at file scale: tiles read from a memmap, plot
+    ids and predictions written into memmaps; a callable `weights` (evaluated between the search and the
+    reduction) falls back to tile-by-tile predict and gives the same numbers."""
+    import pandas as pd
+
+    import sknnr_amd
+    from conftest import yaimpute_weights
+    from sknnr_amd import synth
+
+    x_ref, y, x_q = synth.make_problem(3000, 120_000, 10, t=5, kind="positive")
+    frame = pd.DataFrame(x_ref, index=np.arange(3000) * 7 + 11)
+    src = np.memmap(tmp_path / "pixels.f64", dtype=np.float64, mode="w+", shape=x_q.shape)
+    src[:] = x_q
+    src.flush()
+    ids = np.memmap(tmp_path / "ids.i64", dtype=np.int64, mode="w+", shape=(len(x_q), 3))
+    dist = np.memmap(tmp_path / "dist.f64", dtype=np.float64, mode="w+", shape=(len(x_q), 3))
+    est = sknnr_amd.MSNRegressor(n_neighbors=3).fit(frame, y)
+    tiles = (src[a:a + 25_000] for a in range(0, len(x_q), 25_000))
+    d_out, i_out = est.kneighbors_chunks(tiles, return_dataframe_index=True, out=(dist, ids))
+    d_ref, i_ref = est.kneighbors(x_q, return_dataframe_index=True)
+    np.testing.assert_array_equal(np.asarray(ids), i_ref)
+    np.testing.assert_array_equal(np.asarray(dist), d_ref)
+    assert np.shares_memory(i_out, ids) and (np.asarray(ids) % 7 == 4).all()
+    pred = np.memmap(tmp_path / "pred.f64", dtype=np.float64, mode="w+", shape=(len(x_q), 5))
+    est.predict_chunks((src[a:a + 40_000] for a in range(0, len(x_q), 40_000)), out=pred)
+    np.testing.assert_array_equal(np.asarray(pred), est.predict(x_q))
+    est_w = sknnr_amd.MSNRegressor(n_neighbors=3, weights=yaimpute_weights).fit(frame, y)
+    p_w = est_w.predict_chunks(src[a:a + 50_000] for a in range(0, len(x_q), 50_000))
+    np.testing.assert_array_equal(p_w, est_w.predict(x_q))
+    with pytest.raises(TypeError, match="host arrays"):
+        import torch
+
+        est.kneighbors_chunks([torch.as_tensor(x_q[:10], device="cuda")])
+    with pytest.raises(ValueError, match="out arrays"):
+        est.kneighbors_chunks([x_q[:10]], out=(None, np.empty((5, 3), dtype=np.int64)))
