@@ -35,6 +35,9 @@ __host__ __device__ constexpr int tile2_bytes(int ks) { return ks * 1024 + 128; 
 #ifndef SKNNR_V2_WAVES
 #define SKNNR_V2_WAVES 16
 #endif
+#ifndef SKNNR_V2_UNROLL
+#define SKNNR_V2_UNROLL 1
+#endif
 #ifndef SKNNR_V2_TPS
 #define SKNNR_V2_TPS (SKNNR_V2_WAVES == 16 ? 16 : 8)
 #endif
@@ -277,6 +280,9 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         return;
 #endif
         const unsigned qlane = qwave + qb * (kQueueCap * 512);
+        // the row id is needed on a visit only: the empty asm pins its computation inside this branch (the
+        // compiler would otherwise speculate it into the skip path, one VALU per unit)
+        asm volatile("" : "+s"(tile_no));
         const int id_base = tile_no * 32 + 4 * half;
         int want = cnt[qb];  // entries this lane would hold if the queue were unbounded
 #pragma unroll
@@ -353,7 +359,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         if (st + 1 < n_stages)
             stage_copy(rhi + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
         float g[5], m1;
-#pragma unroll 1
+#pragma unroll SKNNR_V2_UNROLL
         for (int t = 0; t < TPS; ++t) {
             const char* tb = cur + t * TB;
             const int tile_no = st * TPS + t;
