@@ -42,7 +42,7 @@ typedef enum sknnr_status {
     SKNNR_ERR_UNSUPPORTED = -4, /* outside the envelope of the HIP kernels (no CPU fallback exists) */
     SKNNR_ERR_HIP = -5,         /* HIP runtime failure (message carries hipGetErrorString) */
     SKNNR_ERR_NO_DEVICE = -6,   /* no usable gfx950 device */
-    SKNNR_ERR_NONFINITE = -7    /* query rows contain NaN or infinity; the message is scikit-learn's
+    SKNNR_ERR_NONFINITE = -7    /* query (or reference) rows contain NaN or infinity; the message is scikit-learn's
                                    ("Input X contains NaN." / "Input X contains infinity or a value too large
                                    for dtype('float64')."): SKL/utils/validation.py _assert_all_finite, reached
                                    from SKL/neighbors/_base.py:838-845 and REF transformers' transform() */
@@ -130,7 +130,8 @@ const char* sknnr_last_error(void);
  * Build the device-resident index from the transformed reference rows.
  * Replaces KNeighborsRegressor.fit -> NeighborsBase._fit storing _fit_X and _y
  * (SKL/neighbors/_base.py:474-694; called from REF _base.py:107, :266-267).
- *   ref   : host, (n_ref, d) transformed features (the reference's _fit_X)
+ *   ref   : host, (n_ref, d) transformed features (the reference's _fit_X); every value finite, else
+ *           SKNNR_ERR_NONFINITE (the reference's fit raises the same ValueError from its input validation)
  *   y     : host, (n_ref, t) targets (the reference's _y) or NULL (kneighbors only)
  *   device: HIP device ordinal
  */

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -124,6 +125,15 @@ struct DevBuf {
 constexpr int kMaxKs = 8;              // coarse path: d <= 128
 constexpr long kRowQuantum = 6144;  // query-row padding: multiple of every coarse geometry (2048, 1536, 1024, 768, 512, 384, 256 rows per workgroup)
 constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk (each chunk is padded to kRowQuantum)
+// rows per device chunk of one call (SKNNR_CHUNK_ROWS overrides: A/B runs of the launch granularity)
+long chunk_rows() {
+    static const long v = [] {
+        const char* e = std::getenv("SKNNR_CHUNK_ROWS");
+        const long r = e ? std::atol(e) : 0;
+        return r >= kRowQuantum ? std::min<long>(r, 1L << 26) : kChunkRows;
+    }();
+    return v;
+}
 constexpr int kScanMaxKK = 192;
 // Error bound of the split contraction, in units of 2^-24 (|q'| + max|r'|)^2 -- derived in DESIGN.md
 // section 2 from the measured arithmetic of v_mfma_f32_32x32x16_f16 (scripts/microbench/
@@ -429,6 +439,18 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         return fail(SKNNR_ERR_NO_DEVICE, "no HIP device is visible");
     if (device < 0 || device >= n_dev) return fail(SKNNR_ERR_INVALID, "device %d out of range [0, %d)", device, n_dev);
     HIP_TRY(hipSetDevice(device));
+    {
+        // every value finite (the reference's fit validates the same way: SKL/utils/validation.py, ensure_all_finite);
+        // x - x is 0 for finite x and NaN for NaN and +-inf
+        double bad = 0.0;
+        const size_t total = (size_t)n_ref * (size_t)d;
+        for (size_t i = 0; i < total; ++i) bad += ref[i] - ref[i];
+        if (bad != 0.0) {
+            for (size_t i = 0; i < total; ++i)
+                if (ref[i] != ref[i]) return fail(SKNNR_ERR_NONFINITE, "Input X contains NaN.");
+            return fail(SKNNR_ERR_NONFINITE, "Input X contains infinity or a value too large for dtype('float64').");
+        }
+    }
 
     sknnr_index* ix = new (std::nothrow) sknnr_index();
     if (!ix) return fail(SKNNR_ERR_INVALID, "out of host memory");
@@ -615,7 +637,9 @@ extern "C" int sknnr_index_set_affine(sknnr_index* ix, int32_t d_in, const doubl
     if (d_in < 1) return fail(SKNNR_ERR_INVALID, "d_in must be >= 1");
     if (!proj && d_in != ix->d)
         return fail(SKNNR_ERR_INVALID, "without a projection d_in (%d) must equal d (%d)", d_in, ix->d);
+    std::lock_guard<std::mutex> lock(ix->mtx);
     HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());  // a call still running may be reading the previous map
     ix->d_in = d_in;
     ix->has_center = center != nullptr;
     ix->has_scale = scale != nullptr;
@@ -923,7 +947,7 @@ int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
     return SKNNR_OK;
 }
 
-// The second-generation kernel serves ks <= 2 with lists of 6 or 8 (SKNNR_COARSE_V2=0 selects the first one).
+// The second-generation kernel serves the shapes of coarse2_supported() (SKNNR_COARSE_V2=0 selects the first one).
 bool use_coarse2(const sknnr_index* ix, int m_list) {
     static const bool enabled = [] {
         const char* e = std::getenv("SKNNR_COARSE_V2");
@@ -1088,7 +1112,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         HIP_TRY(ix->xt.ensure((size_t)nq * ix->d));
         xq_call = ix->xt.p;
     }
-    const long cap = std::min(kChunkRows, nq);
+    const long cap = std::min(chunk_rows(), nq);
     const long cap_pad = (cap + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
     if (coarse || affine) {
         HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
@@ -1137,8 +1161,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         check_finite_kernel<<<dim3((unsigned)std::min<long>((n_el + 255) / 256, 256L * 16)), dim3(256), 0, st>>>(xdev, n_el, ix->status.p);
         HIP_TRY(hipGetLastError());
     }
-    for (long c0 = 0; c0 < nq; c0 += kChunkRows) {
-        const long n = std::min(kChunkRows, nq - c0);
+    for (long c0 = 0; c0 < nq; c0 += chunk_rows()) {
+        const long n = std::min(chunk_rows(), nq - c0);
         const long n_pad = (n + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
         const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
         if (coarse || affine) {
@@ -1280,7 +1304,16 @@ struct HostPipe {
         double* op = nullptr;
     } pending[2];
     int slot_of = 0;
+    double ms_copy_in = 0, ms_copy_out = 0, ms_wait = 0, ms_enqueue = 0;  // host-thread time per phase (SKNNR_PIPE_TRACE=1)
 };
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+bool pipe_trace() {
+    static const bool v = std::getenv("SKNNR_PIPE_TRACE") != nullptr;
+    return v;
+}
 
 int pipe_open(HostPipe& p, sknnr_index* ix, const sknnr_query_opts* o, bool want_dist, bool want_idx, bool want_pred) {
     p = HostPipe{};
@@ -1292,16 +1325,12 @@ int pipe_open(HostPipe& p, sknnr_index* ix, const sknnr_query_opts* o, bool want
     p.k = o->n_neighbors;
     p.t = ix->t;
     p.d_x = o->apply_affine ? ix->d_in : ix->d;
-    if (!ix->st_h2d) {
-        HIP_TRY(hipStreamCreateWithFlags(&ix->st_h2d, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&ix->st_run, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&ix->st_d2h, hipStreamNonBlocking));
-        for (auto& sl : ix->slot) {
-            HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&sl.ev_d2h, hipEventDisableTiming));
-        }
-    }
+    // (each object on its own: a creation that failed half way is completed by the next call, never skipped)
+    for (hipStream_t* h : {&ix->st_h2d, &ix->st_run, &ix->st_d2h})
+        if (!*h) HIP_TRY(hipStreamCreateWithFlags(h, hipStreamNonBlocking));
+    for (auto& sl : ix->slot)
+        for (hipEvent_t* e : {&sl.ev_h2d, &sl.ev_done, &sl.ev_d2h})
+            if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return SKNNR_OK;
 }
 
@@ -1310,10 +1339,14 @@ int pipe_drain(HostPipe& p, int b) {
     auto& pd = p.pending[b];
     if (!pd.live) return SKNNR_OK;
     auto& sl = p.ix->slot[b];
+    const double t0 = now_ms();
     HIP_TRY(hipEventSynchronize(sl.ev_d2h));
+    const double t1 = now_ms();
     if (pd.oi) parallel_copy(pd.oi, sl.pin_i, (size_t)pd.n * p.k * sizeof(long));
     if (pd.od) parallel_copy(pd.od, sl.pin_d, (size_t)pd.n * p.k * sizeof(double));
     if (pd.op) parallel_copy(pd.op, sl.pin_p, (size_t)pd.n * p.t * sizeof(double));
+    p.ms_wait += t1 - t0;
+    p.ms_copy_out += now_ms() - t1;
     pd.live = false;
     return SKNNR_OK;
 }
@@ -1336,7 +1369,10 @@ int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, doub
     HIP_TRY(sl.dev_d.ensure((size_t)n * k));
     if (p.want_pred) HIP_TRY(sl.dev_p.ensure((size_t)n * t));
 
+    const double t_in = now_ms();
     parallel_copy(sl.pin_x, q, (size_t)n * d_x * sizeof(double));
+    const double t_enq = now_ms();
+    p.ms_copy_in += t_enq - t_in;
     HIP_TRY(hipMemcpyAsync(sl.dev_x.p, sl.pin_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, ix->st_h2d));
     HIP_TRY(hipEventRecord(sl.ev_h2d, ix->st_h2d));
     HIP_TRY(hipStreamWaitEvent(ix->st_run, sl.ev_h2d, 0));
@@ -1359,6 +1395,7 @@ int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, doub
     pd.oi = oi;
     pd.op = op;
     p.o.row_offset += n;
+    p.ms_enqueue += now_ms() - t_enq;
     return SKNNR_OK;
 }
 
@@ -1379,6 +1416,11 @@ int pipe_flush(HostPipe& p) {
     for (int i = 0; i < 2; ++i) {
         int rc = pipe_drain(p, p.slot_of ^ i);  // older tile first
         if (rc) return rc;
+    }
+    if (pipe_trace()) {
+        std::fprintf(stderr, "[pipe] host thread: copy-in %.1f ms, copy-out %.1f ms, waiting for results %.1f ms, enqueue %.1f ms\n",
+                     p.ms_copy_in, p.ms_copy_out, p.ms_wait, p.ms_enqueue);
+        p.ms_copy_in = p.ms_copy_out = p.ms_wait = p.ms_enqueue = 0;
     }
     if (p.o.check_finite) {
         HIP_TRY(hipStreamSynchronize(p.ix->st_run));
@@ -1671,7 +1713,9 @@ extern "C" int sknnr_debug_coarse_matrix(sknnr_index* ix, const double* q, int64
     if (!ix || !q || !out || nq < 1) return fail(SKNNR_ERR_INVALID, "bad argument");
     if (ix->ks == 0) return fail(SKNNR_ERR_UNSUPPORTED, "no coarse image (d > 128)");
     if ((double)nq * (double)ix->n_ref > 16777216.0) return fail(SKNNR_ERR_INVALID, "nq * n_ref must be <= 2^24");
+    std::lock_guard<std::mutex> lock(ix->mtx);
     HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());  // default stream below; the workspace may still be in use on another one
     const long n_pad = (nq + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
     HIP_TRY(ix->xstage.ensure((size_t)nq * ix->d));
     HIP_TRY(hipMemcpy(ix->xstage.p, q, (size_t)nq * ix->d * sizeof(double), hipMemcpyHostToDevice));

@@ -376,3 +376,16 @@ def test_chunked_outputs_into_memmaps_and_callable_weights(N, tmp_path):
         est.kneighbors_chunks([torch.as_tensor(x_q[:10], device="cuda")])
     with pytest.raises(ValueError, match="out arrays"):
         est.kneighbors_chunks([x_q[:10]], out=(None, np.empty((5, 3), dtype=np.int64)))
+
+
+@pytest.mark.parametrize("bad, msg", [(np.nan, "Input X contains NaN"), (np.inf, "Input X contains infinity")])
+@pytest.mark.parametrize("d", [6, 200])
+def test_nonfinite_reference_rows_are_refused(N, bad, msg, d):
+    """The index refuses NaN / infinite reference values with scikit-learn's sentence (both on the MFMA
+    envelope and beyond it, d > 128); the reference's fit stops at the same input validation."""
+    rng = np.random.default_rng(3)
+    x_ref = rng.standard_normal((300, d))
+    x_ref[123, d - 1] = bad
+    with pytest.raises(N.HipBackendError, match=msg) as info:
+        N.Index(x_ref)
+    assert info.value.code == N.ERR_NONFINITE
