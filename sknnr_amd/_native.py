@@ -353,8 +353,8 @@ class QueryStream:
         check(load().sknnr_stream_push(self._h, _host_ptr(q), nq, _host_ptr(out_dist), _host_ptr(out_idx),
                                        _host_ptr(out_pred)))
         self._keep.append((out_idx, out_dist, out_pred))
-        if len(self._keep) > 4:
-            del self._keep[:-4]  # older tiles have left the two pipeline slots
+        if len(self._keep) > 8:
+            del self._keep[:-8]  # older tiles have left the pipeline (four slots: at most the last four pushes are pending)
         return out_idx, out_dist, out_pred
 
     def flush(self):

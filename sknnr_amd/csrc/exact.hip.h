@@ -731,8 +731,11 @@ __device__ void dual_quicksort_ref(double* v0, int* x0, int n0, int* stack) {
 #define SKNNR_SCAN_WPS 3  // 3 workgroups per CU (<= 170 VGPR): 1.5 ms instead of 2.1 ms for 8.5k rows; 4 (128 VGPR, spills) is no faster
 #endif
 constexpr int kScanWaves = 4;
-constexpr int kScanQPW = 2;                          // queries whose heaps one wave replays
-constexpr int kScanNQ = kScanWaves * kScanQPW;       // queries per workgroup pass
+// queries whose heaps one wave replays: three for the expanded formula (165 VGPRs, no spills: 10-17 % faster than
+// two on exact-only calls and tie-heavy data, scripts/scan_probe.py), two for the direct and Hamming formulas
+// (three spill there and lose: 20000 x 20000 x 500 trees 31.5 -> 45.9 ms)
+__host__ __device__ constexpr int scan_qpw(int formula) { return formula == 0 ? 3 : 2; }
+__host__ __device__ constexpr int scan_nq(int formula) { return kScanWaves * scan_qpw(formula); }  // queries per workgroup pass
 constexpr int kScanRefs = 2 * kScanWaves * 64;       // references per step: two per thread
 constexpr int kScanColChunk = 1024;                  // feature columns of the queries held in LDS at a time
 
@@ -741,42 +744,43 @@ struct ScanLayout {
     int dpad, kkp, stk;
     size_t xs, qn, hv, hi, stack, d2, total;
 };
-__host__ __device__ inline ScanLayout scan_layout(int d, int kk) {
+__host__ __device__ inline ScanLayout scan_layout(int d, int kk, int nq) {
     ScanLayout L;
     L.dpad = ((d < kScanColChunk ? d : kScanColChunk) + 1) & ~1;
     L.kkp = kk + (kk & 1);
     L.stk = (2 * kk + 4 + 1) & ~1;
     size_t b = 0;
-    L.xs = b;    b += 8 * (size_t)kScanNQ * L.dpad;
-    L.qn = b;    b += 8 * (size_t)kScanNQ;
-    L.hv = b;    b += 8 * (size_t)kScanNQ * kk;
-    L.hi = b;    b += 4 * (size_t)kScanNQ * L.kkp;
-    L.stack = b; b += 4 * (size_t)kScanNQ * L.stk;
+    L.xs = b;    b += 8 * (size_t)nq * L.dpad;
+    L.qn = b;    b += 8 * (size_t)nq;
+    L.hv = b;    b += 8 * (size_t)nq * kk;
+    L.hi = b;    b += 4 * (size_t)nq * L.kkp;
+    L.stack = b; b += 4 * (size_t)nq * L.stk;
     b = (b + 15) & ~(size_t)15;
-    L.d2 = b;    b += 8 * (size_t)kScanNQ * kScanRefs;
+    L.d2 = b;    b += 8 * (size_t)nq * kScanRefs;
     L.total = b;
     return L;
 }
-__host__ __device__ inline size_t scan_block_bytes(int d, int kk) { return scan_layout(d, kk).total; }
+__host__ __device__ inline size_t scan_block_bytes(int d, int kk, int formula) { return scan_layout(d, kk, scan_nq(formula)).total; }
 
-// One workgroup (4 waves) per pass of kScanNQ queries.  Per step of 512 references every thread
+// One workgroup (4 waves) per pass of scan_nq(FORMULA) queries.  Per step of 512 references every thread
 // loads TWO columns of the transposed copy (coalesced) once and evaluates their float64 distances to
-// all eight queries (query values are LDS broadcasts, each feeding two fma chains), so a query
-// costs 1/8 of a sweep over the reference copy; the 8 x 512 values go to LDS and every wave then
-// offers them, in index order, to the heaps of its own two queries.  Each distance is the same
+// all NQ (8 or 12) queries (query values are LDS broadcasts, each feeding two fma chains), so a query
+// costs 1/NQ of a sweep over the reference copy; the NQ x 512 values go to LDS and every wave then
+// offers them, in index order, to the heaps of its own QPW queries.  Each distance is the same
 // ascending-feature fma chain as before: results do not depend on the grouping.
 template <int FORMULA, bool CHUNKED = false>
 __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = kScanWaves * 64;
-    constexpr int NQ = kScanNQ;
+    constexpr int QPW = scan_qpw(FORMULA);
+    constexpr int NQ = scan_nq(FORMULA);
     const SelectArgs& s = a.s;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int KK = s.kk;
     const int d = s.d;
-    const ScanLayout L = scan_layout(d, KK);
+    const ScanLayout L = scan_layout(d, KK, NQ);
     double* xs = (double*)(smem_raw + L.xs);
     double* qns = (double*)(smem_raw + L.qn);
     double* hv_all = (double*)(smem_raw + L.hv);
@@ -819,9 +823,9 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
             }
             qns[tid] = qn;
         }
-        double root[kScanQPW];
+        double root[QPW];
 #pragma unroll
-        for (int i = 0; i < kScanQPW; ++i) root[i] = DBL_MAX;
+        for (int i = 0; i < QPW; ++i) root[i] = DBL_MAX;
 
         const size_t ld = (size_t)s.n_ref;
         for (int j0 = 0; j0 < s.n_ref; j0 += kScanRefs) {
@@ -910,8 +914,8 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
             }
             __syncthreads();
 #pragma unroll 1
-            for (int i = 0; i < kScanQPW; ++i) {
-                const int qi = wave * kScanQPW + i;
+            for (int i = 0; i < QPW; ++i) {
+                const int qi = wave * QPW + i;
                 if (qi >= n_here) break;
                 double* hv = hv_all + qi * KK;
                 int* hi = hi_all + qi * L.kkp;
@@ -940,8 +944,8 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
         }
 
         if (lane == 0) {
-            for (int i = 0; i < kScanQPW; ++i) {
-                const int qi = wave * kScanQPW + i;
+            for (int i = 0; i < QPW; ++i) {
+                const int qi = wave * QPW + i;
                 if (qi >= n_here) break;
                 const long q = a.list ? (long)a.list[f0 + qi] : f0 + qi;
                 double* hv = hv_all + qi * KK;

@@ -124,15 +124,22 @@ struct DevBuf {
 
 constexpr int kMaxKs = 8;              // coarse path: d <= 128
 constexpr long kRowQuantum = 6144;  // query-row padding: multiple of every coarse geometry (2048, 1536, 1024, 768, 512, 384, 256 rows per workgroup)
-constexpr long kChunkRows = 1L << 22;  // query rows per workspace chunk (each chunk is padded to kRowQuantum)
-// rows per device chunk of one call (SKNNR_CHUNK_ROWS overrides: A/B runs of the launch granularity)
-long chunk_rows() {
-    static const long v = [] {
+constexpr long kChunkRows = 1L << 22;  // rows per chunk of host-side staging loops (transform entry point, X=None results)
+// Query rows per device chunk of one call (each chunk: prep -> pre-filter -> finalise, padded to kRowQuantum).
+// One launch for as many rows as a 4 GiB workspace holds, at most 2^24: every pre-filter launch ends with a
+// partly filled last round of workgroups (a workgroup sweeps the whole image: ~1.3 ms at 50k rows), so fewer,
+// larger launches waste less (10M x 50k x 32, k=5: 183 -> 188 Mq/s against chunks of 4M rows,
+// scripts/chunk_probe.py).  SKNNR_CHUNK_ROWS overrides (A/B runs).
+long chunk_rows(int ks, int m_list) {
+    static const long forced = [] {
         const char* e = std::getenv("SKNNR_CHUNK_ROWS");
         const long r = e ? std::atol(e) : 0;
-        return r >= kRowQuantum ? std::min<long>(r, 1L << 26) : kChunkRows;
+        return r >= kRowQuantum ? std::min<long>(r, 1L << 26) : 0L;
     }();
-    return v;
+    if (forced) return forced;
+    const long per_row = 64L * std::max(ks, 1) + 8 + 16L * std::max(m_list, 2);  // query image + |q'|^2 + two candidate lists
+    const long rows = std::min<long>(1L << 24, (4L << 30) / per_row);
+    return std::max<long>(kRowQuantum, rows / kRowQuantum * kRowQuantum);
 }
 constexpr int kScanMaxKK = 192;
 // Error bound of the split contraction, in units of 2^-24 (|q'| + max|r'|)^2 -- derived in DESIGN.md
@@ -159,6 +166,7 @@ constexpr double eps_units2(int ks) { return 12.0 + 2.0 * ks; }
 // ----------------------------------------------------------------------------------------
 // the handle
 // ----------------------------------------------------------------------------------------
+constexpr int kHostSlots = 4;  // tiles in flight in the host-buffer pipeline
 struct sknnr_index {
     int device = 0;
     long n_ref = 0;
@@ -195,7 +203,7 @@ struct sknnr_index {
     DevBuf<long long> fail_total;  // running count of certificate failures (device)
     DevBuf<long> idx_stage;
 
-    // host-buffer pipeline: pinned staging + device staging, two slots; three streams
+    // host-buffer pipeline: pinned staging + device staging, kHostSlots slots; three streams
     struct HostSlot {
         double* pin_x = nullptr;  size_t pin_x_n = 0;
         double* pin_d = nullptr;  size_t pin_d_n = 0;
@@ -204,7 +212,7 @@ struct sknnr_index {
         DevBuf<double> dev_x, dev_d, dev_p;
         DevBuf<long> dev_i;
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
-    } slot[2];
+    } slot[kHostSlots];
     hipStream_t st_h2d = nullptr, st_run = nullptr, st_d2h = nullptr;
 
     // Workspace hand-over between calls on different streams: the last launch of a call records
@@ -1031,12 +1039,13 @@ void launch_finalize(const FinalizeArgs& f, long n, hipStream_t st) {
 
 int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int* count, long max_items,
                 hipStream_t st) {
-    const size_t sh = scan_block_bytes(s.d, s.kk);
+    const size_t sh = scan_block_bytes(s.d, s.kk, s.formula);
     if (sh > 150 * 1024)
         return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", s.k, s.d);
     ScanArgs a{s, ix->refT.p, list, count};
-    // one 4-wave workgroup per pass of kScanNQ queries; 4 workgroups per CU keep the float64 pipes busy
-    const long passes = (max_items + kScanNQ - 1) / kScanNQ;
+    // one 4-wave workgroup per pass of scan_nq(formula) queries; 4 workgroups per CU keep the float64 pipes busy
+    const int nq_pass = scan_nq(s.formula);
+    const long passes = (max_items + nq_pass - 1) / nq_pass;
     const long blocks = std::max<long>(1, std::min<long>(passes, 256L * 4));
     const bool chunked = s.d > kScanColChunk;  // wide rows (tree node ids) are swept in column chunks
     auto kern = s.formula == 0 ? (chunked ? exact_scan_kernel<0, true> : exact_scan_kernel<0, false>)
@@ -1112,7 +1121,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         HIP_TRY(ix->xt.ensure((size_t)nq * ix->d));
         xq_call = ix->xt.p;
     }
-    const long cap = std::min(chunk_rows(), nq);
+    const long chunk = chunk_rows(ix->ks, coarse_list_len(kk));
+    const long cap = std::min(chunk, nq);
     const long cap_pad = (cap + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
     if (coarse || affine) {
         HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
@@ -1161,8 +1171,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         check_finite_kernel<<<dim3((unsigned)std::min<long>((n_el + 255) / 256, 256L * 16)), dim3(256), 0, st>>>(xdev, n_el, ix->status.p);
         HIP_TRY(hipGetLastError());
     }
-    for (long c0 = 0; c0 < nq; c0 += chunk_rows()) {
-        const long n = std::min(chunk_rows(), nq - c0);
+    for (long c0 = 0; c0 < nq; c0 += chunk) {
+        const long n = std::min(chunk, nq - c0);
         const long n_pad = (n + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
         const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
         if (coarse || affine) {
@@ -1283,14 +1293,14 @@ int ensure_pinned(T*& p, size_t& have, size_t want) {
     return SKNNR_OK;
 }
 
-// Pageable host arrays in, pageable host arrays out, through two pinned/device slots:
-//   host thread : copy tile c into pinned[c&1]             | copy results of tile c-2 out
+// Pageable host arrays in, pageable host arrays out, through kHostSlots pinned/device slots:
+//   host thread : copy tile c into its slot's pinned buffer | copy results of tile c - kHostSlots out
 //   st_h2d      : pinned -> device                          (PCIe)
 //   st_run      : prep / pre-filter / finalise / scan [+ predict]
 //   st_d2h      : device -> pinned                          (PCIe)
 // so that PCIe in, kernels and PCIe out of neighbouring tiles overlap.  The state lives in a HostPipe so
 // that the streamed entry points (sknnr_stream_*) keep the pipeline full ACROSS calls: a pushed tile's
-// results leave the slot when the slot is needed again (two pushes later) or at flush.
+// results leave the slot when the slot is needed again (kHostSlots tiles later) or at flush.
 struct HostPipe {
     sknnr_index* ix = nullptr;
     sknnr_query_opts o{};        // o.row_offset advances with every submitted tile
@@ -1302,7 +1312,7 @@ struct HostPipe {
         double* od = nullptr;
         long* oi = nullptr;
         double* op = nullptr;
-    } pending[2];
+    } pending[kHostSlots];
     int slot_of = 0;
     double ms_copy_in = 0, ms_copy_out = 0, ms_wait = 0, ms_enqueue = 0;  // host-thread time per phase (SKNNR_PIPE_TRACE=1)
 };
@@ -1355,7 +1365,7 @@ int pipe_drain(HostPipe& p, int b) {
 int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, double* op) {
     sknnr_index* ix = p.ix;
     const int b = p.slot_of;
-    p.slot_of ^= 1;
+    p.slot_of = (p.slot_of + 1) % kHostSlots;
     auto& sl = ix->slot[b];
     int rc = pipe_drain(p, b);  // the slot's previous tile must have left before its buffers are reused
     if (rc) return rc;
@@ -1413,8 +1423,8 @@ int pipe_submit_rows(HostPipe& p, const double* q, long nq, double* od, long* oi
 
 // Everything submitted so far is in the caller's arrays when this returns; reports non-finite input.
 int pipe_flush(HostPipe& p) {
-    for (int i = 0; i < 2; ++i) {
-        int rc = pipe_drain(p, p.slot_of ^ i);  // older tile first
+    for (int i = 0; i < kHostSlots; ++i) {
+        int rc = pipe_drain(p, (p.slot_of + i) % kHostSlots);  // oldest tile first (the next slot to be reused)
         if (rc) return rc;
     }
     if (pipe_trace()) {

@@ -389,3 +389,37 @@ def test_nonfinite_reference_rows_are_refused(N, bad, msg, d):
     with pytest.raises(N.HipBackendError, match=msg) as info:
         N.Index(x_ref)
     assert info.value.code == N.ERR_NONFINITE
+
+
+@pytest.mark.parametrize("d", [16, 32, 64])
+@pytest.mark.parametrize("law", ["same_sign", "midpoints", "one_huge_column", "mixed_magnitudes"])
+def test_adversarial_operands_end_to_end_on_the_second_kernel(N, O, d, law):
+    """The operand sets of test_coarse_error_budget_adversarial, at a reference count that runs the
+    second-generation pre-filter (seeded sweep of main products, corrections in the flush; error budget
+    12 + 2 ks units): an entry that the kernel mis-ranks by more than its budget would surface here as a
+    wrong neighbour or as a certified row that differs from the oracle."""
+    rng = np.random.default_rng(1000 + d + len(law))
+    n_half, nq, k = 4096, 3000, 5
+    if law == "same_sign":
+        r = rng.uniform(0.5, 1.0, (n_half, d)) * 127.0
+        q = rng.uniform(0.5, 1.0, (nq, d)) * 127.0
+    elif law == "midpoints":
+        r = (rng.integers(1024, 2047, (n_half, d)) + 0.5) / 16.0
+        q = (rng.integers(1024, 2047, (nq, d)) + 0.5) / 16.0
+    elif law == "one_huge_column":
+        r = rng.uniform(0.5, 1.0, (n_half, d))
+        q = rng.uniform(0.5, 1.0, (nq, d))
+        r[:, 0] *= 1e6
+        q[:, 0] *= 1e6
+    else:
+        r = rng.uniform(0.5, 1.0, (n_half, d)) * np.exp2(-rng.integers(0, 12, (n_half, d)))
+        q = rng.uniform(0.5, 1.0, (nq, d)) * np.exp2(-rng.integers(0, 12, (nq, d)))
+    x_ref = np.concatenate([r, -r])
+    ix = N.Index(x_ref)
+    dist, idx = ix.kneighbors_host(q, ix.make_opts(k))
+    od, oi = O.kneighbors(x_ref, q, k, "expanded")
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(dist, od)
+    st = ix.stats()
+    assert st["coarse_queries"] == nq, st  # the MFMA path answered (no whole-call exact scan)
+    ix.close()
