@@ -134,8 +134,11 @@ __device__ __forceinline__ void tile_issue_and_test(floatx16& a, floatx16& c, co
         asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[h], %[q], %[c]\n\t" : [c] "+v"(c) : [h] "v"(ah[s]), [q] "v"(q[s]));
 }
 
-template <int KS, int M>
-__global__ void __launch_bounds__(kCoarse2Waves * 64, 4)
+// WAVES = 16 (one workgroup of 1024 query rows per CU) for the bulk of a call; WAVES = 4 (256 rows) for the rows of a
+// last, thinly filled round of workgroups and for small calls: spread over four times as many CUs with one wave per
+// SIMD, where a wave no longer shares its matrix pipe (host side: launch_coarse2_ks).
+template <int KS, int M, int WAVES = kCoarse2Waves>
+__global__ void __launch_bounds__(WAVES * 64, 4)
 coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: KS KiB][|r'|^2: 128 B]
                const char* __restrict__ rlo,    // n_stages * TPS records [lo: KS KiB]
                int n_stages,
@@ -149,7 +152,6 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
     constexpr int TB = tile2_bytes(KS);
     constexpr int STAGE = TPS * TB;
     constexpr int NQB = kCoarse2Nqb;
-    constexpr int WAVES = kCoarse2Waves;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;

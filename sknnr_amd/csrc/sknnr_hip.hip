@@ -940,18 +940,46 @@ int launch_coarse_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
     return SKNNR_OK;
 }
 
-template <int KS, int M>
-int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
-    constexpr int QPB = kCoarse2Waves * kCoarse2Nqb * 32;
-    constexpr size_t sh = 2 * (size_t)tiles_per_stage2(KS) * tile2_bytes(KS) + (size_t)kCoarse2Waves * queue2_bytes_per_wave();
+constexpr int kCoarse2TailWaves = 4;  // workgroup size (waves) of the thin-round variant
+constexpr int kCusPerDevice = 256;
+
+template <int KS, int M, int WAVES>
+int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStream_t st) {
+    constexpr int QPB = WAVES * kCoarse2Nqb * 32;
+    constexpr size_t sh = 2 * (size_t)tiles_per_stage2(KS) * tile2_bytes(KS) + (size_t)WAVES * queue2_bytes_per_wave();
     static_assert(kRowQuantum % QPB == 0, "query rows are padded to multiples of kRowQuantum");
     static_assert(sh <= 160 * 1024, "LDS budget");
-    auto kern = coarse2_kernel<KS, M>;
+    auto kern = coarse2_kernel<KS, M, WAVES>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(kCoarse2Waves * 64), sh, st>>>(
-        ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
-        M - (kk + 1), ix->cand_val.p, ix->cand_idx.p);
+    // rows [row0, row0 + rows) of the chunk: the kernel numbers its query blocks from its first argument row
+    kern<<<dim3((unsigned)(rows / QPB)), dim3(WAVES * 64), sh, st>>>(
+        ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p + (size_t)(row0 / 32) * 2 * KS * 64, ix->qnc.p + row0,
+        (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02), M - (kk + 1), ix->cand_val.p + (size_t)row0 * 2 * M,
+        ix->cand_idx.p + (size_t)row0 * 2 * M);
     HIP_TRY(hipGetLastError());
+    return SKNNR_OK;
+}
+
+// A workgroup of 16 waves sweeps the whole image for its 1024 rows (~1.2 ms at 50k reference rows), so the
+// last round of a launch leaves most CUs idle when it holds few workgroups (10M rows: 9768 workgroups =
+// 38 rounds + 40), and a small call never fills the device.  Rows of such a thin round (at most a quarter of
+// the CUs' worth) go to 4-wave workgroups instead: four times as many CUs, one wave per SIMD.
+template <int KS, int M>
+int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
+    constexpr long QPB = kCoarse2Waves * kCoarse2Nqb * 32;
+    static const bool split = [] {
+        const char* e = std::getenv("SKNNR_COARSE_TAIL");
+        return !(e && std::atoi(e) == 0);
+    }();
+    const long n_wg = nq_pad / QPB;
+    long tail_wg = n_wg % kCusPerDevice;
+    if (!split || tail_wg > kCusPerDevice / (kCoarse2Waves / kCoarse2TailWaves)) tail_wg = 0;
+    const long bulk_rows = (n_wg - tail_wg) * QPB;
+    if (bulk_rows > 0) {
+        int rc = launch_coarse2_waves<KS, M, kCoarse2Waves>(ix, 0, bulk_rows, kk, st);
+        if (rc) return rc;
+    }
+    if (tail_wg > 0) return launch_coarse2_waves<KS, M, kCoarse2TailWaves>(ix, bulk_rows, tail_wg * QPB, kk, st);
     return SKNNR_OK;
 }
 
