@@ -6,7 +6,7 @@
 
 One "step" = one ``kneighbors`` pass of the transformed estimator path over one batch of
 synthetic query rows already resident in HBM:
-    affine transform (32 -> 32, the GNN/CCA form)  ->  f16x3 MFMA pre-filter over all
+    affine transform (32 -> 32, the GNN/CCA form)  ->  split-f16 MFMA pre-filter over all
     references  ->  float64 re-score + certificate + sknnr reorder  ->  (dist, idx) in HBM,
 and, with N > 1, the RCCL all-gather of the per-rank (dist, idx) blocks.
 
@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--dims", type=int, default=32)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--targets", type=int, default=40)
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="rows of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rows of the CPU baseline sample (about 12 s on the GPU box's host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (skip configs 2-5, host paths, laws)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (dist, idx)")
@@ -369,7 +369,7 @@ def main():
             "metric": "Mqueries/sec + achieved HBM GB/s, 10M x 50k x 32 k=5, 1/2/4/8 MI355X",
             "value": value, "unit": "Mqueries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f16x3 split MFMA (f32 accumulate) pre-filter + f64 exact re-score",
+            "dtype": "f16 split MFMA (hi.hi swept, lo.hi + hi.lo corrections; f32 accumulate) pre-filter + f64 exact re-score",
             "data": "synthetic",
             "config": {
                 "workload": f"GNN-style kneighbors: affine {args.dims}->{d_t} (CCA fit on synthetic refs) + "
