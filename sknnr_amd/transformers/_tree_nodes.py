@@ -49,7 +49,17 @@ def _target_plan(y):
     """Per target: name, values promoted to the narrowest numpy dtype that holds them, and
     'regression' (numeric) or 'classification' (anything else, pandas categoricals included)."""
     plan = []
-    for name, values, declared in _columns_of(y):
+    columns = _columns_of(y)
+    # target names key estimator_type_dict_: a name met twice is refused (1 and "1" are different keys)
+    # REF utils/__init__.py:167-172
+    seen, twice = set(), []
+    for name, _, _ in columns:
+        if name in seen and name not in twice:
+            twice.append(name)
+        seen.add(name)
+    if twice:
+        raise ValueError(f"Duplicate feature names found: {twice}.")
+    for name, values, declared in columns:
         if any(_is_missing(v) for v in values):
             raise ValueError(f"Target {name} has NaN-like elements.")
         categorical = declared is not None and str(declared) == "category"

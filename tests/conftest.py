@@ -48,7 +48,8 @@ def moscow_frames():
     from sknnr_amd.datasets import load_moscow_stjoes
 
     X, y = load_moscow_stjoes(return_X_y=True, as_frame=True)
-    return {"X_train": X.iloc[:132], "X_test": X.iloc[132:], "y_train": y.iloc[:132], "y_test": y.iloc[132:]}
+    return {"X_train": X.iloc[:132], "X_test": X.iloc[132:], "y_train": y.iloc[:132], "y_test": y.iloc[132:],
+            "X_all": X, "y_all": y}
 
 
 def yaimpute_weights(d):

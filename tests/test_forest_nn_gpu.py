@@ -188,3 +188,85 @@ def test_wide_synthetic_estimator_goldens(name):
     np.testing.assert_allclose(est.independent_prediction_[::8], g["indep_pred_rows"], rtol=1e-5, atol=1e-8)
     st = est.regressor_.engine_.stats()
     assert st["coarse_queries"] > 0 and st["exact_fallbacks"] < 0.02 * st["queries"], st
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own tree-estimator tests (REF tests/test_estimators.py:380-499), same inputs and assertions
+# ---------------------------------------------------------------------------------------------
+def _expected_forest_weights(forest_weights, n_forests):
+    if isinstance(forest_weights, str):
+        return np.full(n_forests, 1.0 / n_forests)
+    arr = np.asarray(forest_weights, dtype=np.float64)
+    return arr / arr.sum()
+
+
+def _tree_estimators():
+    import sknnr_amd
+
+    return {"rfnn": sknnr_amd.RFNNRegressor, "gbnn": sknnr_amd.GBNNRegressor}
+
+
+@pytest.mark.parametrize("which", ["rfnn", "gbnn"])
+@pytest.mark.parametrize("forest_weights", ["uniform", [0.5, 1.5], (1.0, 2.0)])
+def test_tree_estimator_handles_forest_weights(moscow_frames, which, forest_weights):
+    """REF tests/test_estimators.py:380-405: the weights of a forest's trees add up to the forest's share."""
+    y = moscow_frames["y_all"].iloc[:, :2]
+    est = _tree_estimators()[which](forest_weights=forest_weights).fit(moscow_frames["X_all"], y)
+    assert hasattr(est.transformer_, "tree_weights_")
+    per_forest = est.hamming_weights_.reshape(est.transformer_.n_forests_, -1).sum(axis=1)
+    assert np.allclose(per_forest, _expected_forest_weights(forest_weights, est.transformer_.n_forests_), atol=1e-3)
+
+
+@pytest.mark.parametrize("forest_weights", ["uniform", [0.5, 1.5], (1.0, 2.0)])
+def test_gbnn_multiclass_weights(moscow_frames, forest_weights):
+    """REF tests/test_estimators.py:408-441: a three-class classification forest holds 3 x n_estimators trees
+    whose weights share the forest's weight."""
+    import sknnr_amd
+
+    X, y = moscow_frames["X_all"], moscow_frames["y_all"]
+    y_fit = y[["Total_BA"]].assign(
+        ABGR_CLASS=np.digitize(y.iloc[:, 0], np.percentile(y.iloc[:, 0], [33, 66])).astype(str))
+    est = sknnr_amd.GBNNRegressor(forest_weights=forest_weights).fit(X, y, y_fit=y_fit)
+    assert hasattr(est.transformer_, "tree_weights_")
+    per_block = est.hamming_weights_.reshape(-1, est.transformer_.n_estimators).sum(axis=1)
+    n_classes = np.asarray(est.transformer_.n_trees_per_iteration_)
+    expected = np.repeat(_expected_forest_weights(forest_weights, est.transformer_.n_forests_) / n_classes, n_classes)
+    assert np.allclose(per_block, expected, atol=1e-3)
+    # ... and the search over all 400 node-id columns answers (the classification forest's columns included)
+    dist, idx = est.kneighbors(X.iloc[:20])
+    assert idx.shape == (20, 5) and np.isfinite(dist).all()
+
+
+@pytest.mark.parametrize("which", ["rfnn", "gbnn"])
+@pytest.mark.parametrize("forest_weights", ["uniform", [0.5, 1.5], (1.0, 2.0)])
+@pytest.mark.parametrize("tree_weighting_method", ["uniform", "train_improvement"])
+def test_hamming_weights_sum_to_one(moscow_frames, which, forest_weights, tree_weighting_method):
+    """REF tests/test_estimators.py:444-462."""
+    n_targets = 1 if forest_weights == "uniform" else len(forest_weights)
+    y = moscow_frames["y_all"].iloc[:, :n_targets]
+    kwargs = {"tree_weighting_method": tree_weighting_method} if which == "gbnn" else {}
+    est = _tree_estimators()[which](forest_weights=forest_weights, **kwargs).fit(moscow_frames["X_all"], y)
+    assert np.isclose(est.hamming_weights_.sum(), 1.0)
+
+
+@pytest.mark.parametrize("which", ["rfnn", "gbnn"])
+@pytest.mark.parametrize(
+    ("forest_weights", "expected_msg"),
+    [
+        ([0.5], "Expected `forest_weights` to have length 2"),
+        (1, "Expected `forest_weights` to have length 2"),
+        ("ab", "`forest_weights` must be a sequence of numeric values"),
+        (["a", "b"], "`forest_weights` must be a sequence of numeric values"),
+        ([np.inf, 0.5], "Expected elements in `forest_weights` to be finite"),
+        ([0.5, np.nan], "Expected elements in `forest_weights` to be finite"),
+        ([0.5, -0.5], "Expected elements in `forest_weights` to be non-negative"),
+        ([0, 0], "At least one element in `forest_weights` must be positive"),
+    ],
+    ids=["invalid_length", "numeric_scalar", "non_numeric_scalar", "non_numeric_sequence", "infinite_weight",
+         "nan_weight", "negative_weights", "zero_weights"],
+)
+def test_tree_estimator_raises_on_invalid_forest_weights(moscow_frames, which, forest_weights, expected_msg):
+    """REF tests/test_estimators.py:465-499: same inputs, same messages."""
+    y = moscow_frames["y_all"].iloc[:, :2]
+    with pytest.raises(ValueError, match=expected_msg):
+        _tree_estimators()[which](forest_weights=forest_weights).fit(moscow_frames["X_all"], y)
