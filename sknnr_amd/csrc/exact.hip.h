@@ -639,7 +639,27 @@ struct ScanArgs {
     const double* refT; // (d, n_ref) transposed reference rows
     const int* list;    // query ids to process, or null = all 0..count-1
     const int* count;   // device count (with list), else null and s.nq is used
+    // Few queries (fewer passes than workgroups of the grid): the reference rows of a pass are split into S slices,
+    // one workgroup each (scan_slices); the slice heaps go to slice_v / slice_i [query slot][S][kk] and
+    // scan_merge_kernel combines them.  Null = never sliced.
+    double* slice_v;
+    int* slice_i;
+    int* list2;         // scan_merge_kernel: queries whose merged heaps are not unique (exact ties) -> sequential scan
+    int* count2;
 };
+
+constexpr int kScanSliceMaxKK = 32;  // sliced mode serves kk <= 32 (the serial merge is O(S kk) insertions)
+constexpr int kScanMaxSlices = 32;
+// slices per pass, computed the same way by the scan, the merge and (as an upper bound) the host
+__host__ __device__ inline int scan_slices(long n_items, int nq_pass, int n_ref, int kk, int grid_wg) {
+    const long passes = (n_items + nq_pass - 1) / nq_pass;
+    if (passes <= 0 || kk > kScanSliceMaxKK) return 1;
+    const int n_steps = (n_ref + 511) / 512;  // kScanRefs references per step: a slice is at least one step
+    long sl = grid_wg / passes;
+    if (sl > kScanMaxSlices) sl = kScanMaxSlices;
+    if (sl > n_steps) sl = n_steps;
+    return sl < 2 ? 1 : (int)sl;
+}
 
 __device__ __forceinline__ void heap_push_ref(double* hv, int* hi, int k, double v, int id) {
     // caller has checked v < hv[0]
@@ -727,6 +747,59 @@ __device__ void dual_quicksort_ref(double* v0, int* x0, int n0, int* stack) {
     }
 }
 
+// The end of a query's replay: its kk heap entries -> sort (expanded formula: the reference's quicksort on the heap
+// array) -> drop self (X=None) -> sqrt -> sknnr's reorder -> outputs.  Serial over <= kk entries.
+template <int FORMULA>
+__device__ void scan_finish_query(const SelectArgs& s, long q, double* hv, int* hi, int* stack) {
+    const int KK = s.kk;
+    if (FORMULA == 0) dual_quicksort_ref(hv, hi, KK, stack);
+    const long self_id = s.row_offset + q;
+    int drop = -1;
+    if (s.exclude_self) {
+        drop = 0;
+        for (int e = 0; e < KK; ++e)
+            if ((long)hi[e] == self_id) { drop = e; break; }
+    }
+    int n = 0;
+    for (int e = 0; e < KK; ++e) {
+        if (e == drop) continue;
+        hv[n] = FORMULA == 2 ? hv[e] : sqrt(hv[e] > 0.0 ? hv[e] : 0.0);  // (a Hamming distance is not a square)
+        hi[n] = hi[e];
+        ++n;
+    }
+    if (n > s.k) n = s.k;
+    if (s.deterministic) {
+        double dmax = 0.0;
+        for (int e = 0; e < n; ++e) dmax = fmax(dmax, hv[e]);
+        const double row_scale = fmax(dmax, 1.0);
+        // stable insertion sort by (rounded, |idx - row|, idx)  (REF _base.py:166-175)
+        for (int e = 1; e < n; ++e) {
+            const double dv = hv[e];
+            const int iv = hi[e];
+            const double k0 = round_key(dv / row_scale, s.pow10, s.pow10_is_divisor);
+            long k1 = (long)iv - self_id;
+            k1 = k1 < 0 ? -k1 : k1;
+            int jj = e - 1;
+            while (jj >= 0) {
+                const double k0j = round_key(hv[jj] / row_scale, s.pow10, s.pow10_is_divisor);
+                long k1j = (long)hi[jj] - self_id;
+                k1j = k1j < 0 ? -k1j : k1j;
+                const bool greater = (k0j > k0) || (k0j == k0 && (k1j > k1 || (k1j == k1 && hi[jj] > iv)));
+                if (!greater) break;
+                hv[jj + 1] = hv[jj];
+                hi[jj + 1] = hi[jj];
+                --jj;
+            }
+            hv[jj + 1] = dv;
+            hi[jj + 1] = iv;
+        }
+    }
+    for (int e = 0; e < n; ++e) {
+        if (s.out_dist) s.out_dist[q * s.k + e] = hv[e];
+        s.out_idx[q * s.k + e] = hi[e];
+    }
+}
+
 #ifndef SKNNR_SCAN_WPS
 #define SKNNR_SCAN_WPS 3  // 3 workgroups per CU (<= 170 VGPR): 1.5 ms instead of 2.1 ms for 8.5k rows; 4 (128 VGPR, spills) is no faster
 #endif
@@ -789,7 +862,16 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
     double* d2buf = (double*)(smem_raw + L.d2);
 
     const long n_items = a.list ? (long)*a.count : s.nq;
-    for (long f0 = (long)blockIdx.x * NQ; f0 < n_items; f0 += (long)gridDim.x * NQ) {
+    // sliced mode: workgroup b sweeps slice b % S of pass b / S and leaves its heaps to scan_merge_kernel
+    const int S = a.slice_v ? scan_slices(n_items, NQ, s.n_ref, KK, (int)gridDim.x) : 1;
+    const int slice = S > 1 ? (int)(blockIdx.x % S) : 0;
+    const int n_steps = (s.n_ref + kScanRefs - 1) / kScanRefs;
+    const int j_begin = (int)((long)slice * n_steps / S) * kScanRefs;
+    const int j_end_raw = (int)((long)(slice + 1) * n_steps / S) * kScanRefs;
+    const int j_end = j_end_raw < s.n_ref ? j_end_raw : s.n_ref;
+    const long f_first = (S > 1 ? (long)(blockIdx.x / S) : (long)blockIdx.x) * NQ;
+    const long f_stride = S > 1 ? (1L << 40) : (long)gridDim.x * NQ;
+    for (long f0 = f_first; f0 < n_items; f0 += f_stride) {
         const int n_here = (int)((n_items - f0) < NQ ? (n_items - f0) : NQ);
         __syncthreads();  // previous pass's LDS state is dead
         // padding slots repeat the pass's last query; nothing is written for them
@@ -828,7 +910,7 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
         for (int i = 0; i < QPW; ++i) root[i] = DBL_MAX;
 
         const size_t ld = (size_t)s.n_ref;
-        for (int j0 = 0; j0 < s.n_ref; j0 += kScanRefs) {
+        for (int j0 = j_begin; j0 < j_end; j0 += kScanRefs) {
             const int ja = j0 + tid, jb = j0 + NT + tid;
             const double* cola = a.refT + (ja < s.n_ref ? ja : 0);
             const double* colb = a.refT + (jb < s.n_ref ? jb : 0);
@@ -943,63 +1025,104 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
             }
         }
 
+        if (S > 1) {
+            // raw heaps of this slice (unfilled slots hold DBL_MAX), [query slot][slice][kk]
+            __syncthreads();
+            for (int e = tid; e < n_here * KK; e += NT) {
+                const int qi = e / KK, c = e - qi * KK;
+                const size_t o = ((size_t)(f0 + qi) * S + slice) * KK + c;
+                a.slice_v[o] = hv_all[qi * KK + c];
+                a.slice_i[o] = hi_all[qi * L.kkp + c];
+            }
+            continue;
+        }
         if (lane == 0) {
             for (int i = 0; i < QPW; ++i) {
                 const int qi = wave * QPW + i;
                 if (qi >= n_here) break;
                 const long q = a.list ? (long)a.list[f0 + qi] : f0 + qi;
-                double* hv = hv_all + qi * KK;
-                int* hi = hi_all + qi * L.kkp;
-                if (FORMULA == 0) dual_quicksort_ref(hv, hi, KK, stack_all + qi * L.stk);
-                // drop self (X=None), sqrt, reorder: serial over <= KK entries
-                const long self_id = s.row_offset + q;
-                int drop = -1;
-                if (s.exclude_self) {
-                    drop = 0;
-                    for (int e = 0; e < KK; ++e)
-                        if ((long)hi[e] == self_id) { drop = e; break; }
-                }
-                int n = 0;
-                for (int e = 0; e < KK; ++e) {
-                    if (e == drop) continue;
-                    hv[n] = FORMULA == 2 ? hv[e] : sqrt(hv[e] > 0.0 ? hv[e] : 0.0);  // (a Hamming distance is not a square)
-                    hi[n] = hi[e];
-                    ++n;
-                }
-                if (n > s.k) n = s.k;
-                if (s.deterministic) {
-                    double dmax = 0.0;
-                    for (int e = 0; e < n; ++e) dmax = fmax(dmax, hv[e]);
-                    const double row_scale = fmax(dmax, 1.0);
-                    // stable insertion sort by (rounded, |idx - row|, idx)  (REF _base.py:166-175)
-                    for (int e = 1; e < n; ++e) {
-                        const double dv = hv[e];
-                        const int iv = hi[e];
-                        const double k0 = round_key(dv / row_scale, s.pow10, s.pow10_is_divisor);
-                        long k1 = (long)iv - self_id;
-                        k1 = k1 < 0 ? -k1 : k1;
-                        int jj = e - 1;
-                        while (jj >= 0) {
-                            const double k0j = round_key(hv[jj] / row_scale, s.pow10, s.pow10_is_divisor);
-                            long k1j = (long)hi[jj] - self_id;
-                            k1j = k1j < 0 ? -k1j : k1j;
-                            const bool greater = (k0j > k0) || (k0j == k0 && (k1j > k1 || (k1j == k1 && hi[jj] > iv)));
-                            if (!greater) break;
-                            hv[jj + 1] = hv[jj];
-                            hi[jj + 1] = hi[jj];
-                            --jj;
-                        }
-                        hv[jj + 1] = dv;
-                        hi[jj + 1] = iv;
-                    }
-                }
-                for (int e = 0; e < n; ++e) {
-                    if (s.out_dist) s.out_dist[q * s.k + e] = hv[e];
-                    s.out_idx[q * s.k + e] = hi[e];
-                }
+                scan_finish_query<FORMULA>(s, q, hv_all + qi * KK, hi_all + qi * L.kkp, stack_all + qi * L.stk);
             }
         }
     }
+}
+
+// Sliced scans: combine the S slice heaps of every query (one wave per query, lane 0 works) and finish the
+// query.  Under the direct and Hamming formulas the selection rule is "smallest (d2, index) first", which the
+// union of the slices' lists answers exactly.  Under the expanded formula the reference's heap decides
+// exact ties by its history: the union is its answer only when that answer is unique -- no tie at the k-th
+// value (seen, or possibly dropped inside a full slice), with non-deterministic ordering no equal values among
+// the kept rows, and with X=None the row itself among them; every other query goes to list2 for the sequential
+// scan.
+template <int FORMULA>
+__global__ void __launch_bounds__(256) scan_merge_kernel(ScanArgs a, int grid_wg_of_scan) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const SelectArgs& s = a.s;
+    const int KK = s.kk;
+    const long n_items = a.list ? (long)*a.count : s.nq;
+    const int S = scan_slices(n_items, scan_nq(FORMULA), s.n_ref, KK, grid_wg_of_scan);
+    if (S == 1) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long slot = (long)blockIdx.x * 4 + wave;
+    if (slot >= n_items || lane != 0) return;
+    // per wave: hv[KK + 1] | hi[KK + 1] | stack
+    const int kkp = (KK + 2) & ~1, stk = (2 * KK + 4 + 1) & ~1;
+    char* base = smem_raw + (size_t)wave * (8 * (size_t)kkp + 4 * (size_t)kkp + 4 * (size_t)stk);
+    double* hv = (double*)base;
+    int* hi = (int*)(base + 8 * (size_t)kkp);
+    int* stack = hi + kkp;
+    const long q = a.list ? (long)a.list[slot] : slot;
+
+    int n = 0;  // entries of the merged list, at most KK + 1, ascending by (value, index)
+    for (int sl = 0; sl < S; ++sl) {
+        const double* sv = a.slice_v + ((size_t)slot * S + sl) * KK;
+        const int* si = a.slice_i + ((size_t)slot * S + sl) * KK;
+        for (int e = 0; e < KK; ++e) {
+            const double v = sv[e];
+            if (v == DBL_MAX) continue;  // unfilled slot
+            const int id = si[e];
+            if (n == KK + 1 && !(v < hv[KK] || (v == hv[KK] && id < hi[KK]))) continue;
+            int pos = n < KK + 1 ? n : KK;
+            while (pos > 0 && (hv[pos - 1] > v || (hv[pos - 1] == v && hi[pos - 1] > id))) {
+                hv[pos] = hv[pos - 1];
+                hi[pos] = hi[pos - 1];
+                --pos;
+            }
+            hv[pos] = v;
+            hi[pos] = id;
+            if (n < KK + 1) ++n;
+        }
+    }
+    bool unique = n >= KK;
+    if (FORMULA == 0 && unique) {
+        const double vk = hv[KK - 1];
+        if (n > KK && hv[KK] == vk) unique = false;  // a tie at the k-th value
+        // a FULL slice whose largest kept value is the k-th value overall may have rejected or evicted rows equal
+        // to it (whatever a slice rejects or evicts is >= its final maximum: irrelevant when that is above vk; a
+        // full slice cannot end below vk, or k rows would lie below the k-th value)
+        for (int sl = 0; sl < S && unique; ++sl) {
+            const double* sv = a.slice_v + ((size_t)slot * S + sl) * KK;
+            int filled = 0;
+            double smax = -INFINITY;
+            for (int e = 0; e < KK; ++e)
+                if (sv[e] != DBL_MAX) { ++filled; smax = fmax(smax, sv[e]); }
+            if (filled == KK && smax == vk) unique = false;
+        }
+        if (unique && !s.deterministic)
+            for (int e = 1; e < KK; ++e)
+                if (hv[e] == hv[e - 1]) unique = false;  // the heap's history orders equal values
+        if (unique && s.exclude_self) {
+            bool found = false;
+            for (int e = 0; e < KK; ++e) found = found || (long)hi[e] == s.row_offset + q;
+            if (!found) unique = false;  // "drop the first entry" depends on the order among equal values
+        }
+    }
+    if (!unique) {
+        const int o = atomicAdd(a.count2, 1);
+        a.list2[o] = (int)q;
+        return;
+    }
+    scan_finish_query<FORMULA>(s, q, hv, hi, stack);
 }
 
 // ---------------------------------------------------------------------------------------

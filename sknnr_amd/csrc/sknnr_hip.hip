@@ -198,7 +198,8 @@ struct sknnr_index {
     DevBuf<double> xt, qnc, xstage, dist_stage, pred_stage;
     DevBuf<uint4> qimg;
     DevBuf<float> cand_val;
-    DevBuf<int> cand_idx, fail_list, fail_count;
+    DevBuf<int> cand_idx, fail_list, fail_count, fail_list2, slice_i;
+    DevBuf<double> slice_v;  // sliced exact scans: the slice heaps (exact.hip.h, scan_slices)
     DevBuf<int> status;            // bit 0: a query value was NaN, bit 1: infinite (since the last poll)
     DevBuf<long long> fail_total;  // running count of certificate failures (device)
     DevBuf<long> idx_stage;
@@ -1065,24 +1066,68 @@ void launch_finalize(const FinalizeArgs& f, long n, hipStream_t st) {
     else launch_finalize_m<32>(f, n, st);
 }
 
+constexpr int kScanGridWg = 256 * 4;  // workgroups of a scan launch (also what scan_slices splits among the passes)
+
+template <int FORMULA>
+int launch_scan_formula(sknnr_index* ix, const ScanArgs& a0, long max_items, bool chunked, size_t sh, hipStream_t st) {
+    constexpr int nq_pass = scan_nq(FORMULA);
+    const SelectArgs& s = a0.s;
+    auto kern = chunked ? exact_scan_kernel<FORMULA, true> : exact_scan_kernel<FORMULA, false>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    ScanArgs a = a0;
+    // Few queries: their passes would leave most of the device idle while each sweeps every reference row
+    // (0.5 ms at 50k rows whatever the count) -- the kernel then splits the rows of a pass over several
+    // workgroups and scan_merge_kernel combines the slice heaps.  The count is on the device when the queries
+    // come from the fail list, so the decision is taken there; the host only provides the buffers.
+    const bool may_slice = s.kk <= kScanSliceMaxKK && scan_slices(1, nq_pass, s.n_ref, s.kk, kScanGridWg) > 1;
+    if (may_slice) {
+        // at most kScanGridWg / 2 passes are sliced: (passes * nq_pass) slots x S slices <= kScanGridWg * nq_pass heaps
+        const size_t heaps = (size_t)kScanGridWg * nq_pass * s.kk;
+        HIP_TRY(ix->slice_v.ensure(heaps));
+        HIP_TRY(ix->slice_i.ensure(heaps));
+        HIP_TRY(ix->fail_list2.ensure((size_t)kScanGridWg * nq_pass));
+        HIP_TRY(hipMemsetAsync(ix->fail_count.p + 2, 0, sizeof(int), st));
+        a.slice_v = ix->slice_v.p;
+        a.slice_i = ix->slice_i.p;
+        a.list2 = ix->fail_list2.p;
+        a.count2 = ix->fail_count.p + 2;
+    }
+    const long passes = (max_items + nq_pass - 1) / nq_pass;
+    // (sliced mode needs the whole grid even for one pass; otherwise one workgroup per pass is enough)
+    const long blocks = may_slice ? kScanGridWg : std::max<long>(1, std::min<long>(passes, kScanGridWg));
+    kern<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    if (!may_slice) return SKNNR_OK;
+    // one wave per sliced query (none if the scan was not sliced: the kernel returns at once)
+    const long sliced_max = std::min<long>(max_items, (long)kScanGridWg * nq_pass / 2);
+    const int kkp = (s.kk + 2) & ~1, stk = (2 * s.kk + 4 + 1) & ~1;
+    const size_t msh = 4 * ((size_t)12 * kkp + (size_t)4 * stk);
+    scan_merge_kernel<FORMULA><<<dim3((unsigned)((sliced_max + 3) / 4)), dim3(256), msh, st>>>(a, (int)blocks);
+    HIP_TRY(hipGetLastError());
+    // queries whose merged heaps are not unique (exact ties): the sequential scan, never sliced
+    ScanArgs b = a0;
+    b.list = ix->fail_list2.p;
+    b.count = ix->fail_count.p + 2;
+    b.slice_v = nullptr;
+    b.slice_i = nullptr;
+    const long blocks2 = std::max<long>(1, std::min<long>((sliced_max + nq_pass - 1) / nq_pass, kScanGridWg));
+    kern<<<dim3((unsigned)blocks2), dim3(kScanWaves * 64), sh, st>>>(b);
+    HIP_TRY(hipGetLastError());
+    return SKNNR_OK;
+}
+
 int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int* count, long max_items,
                 hipStream_t st) {
     const size_t sh = scan_block_bytes(s.d, s.kk, s.formula);
     if (sh > 150 * 1024)
         return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", s.k, s.d);
-    ScanArgs a{s, ix->refT.p, list, count};
-    // one 4-wave workgroup per pass of scan_nq(formula) queries; 4 workgroups per CU keep the float64 pipes busy
-    const int nq_pass = scan_nq(s.formula);
-    const long passes = (max_items + nq_pass - 1) / nq_pass;
-    const long blocks = std::max<long>(1, std::min<long>(passes, 256L * 4));
+    ScanArgs a{s, ix->refT.p, list, count, nullptr, nullptr, nullptr, nullptr};
     const bool chunked = s.d > kScanColChunk;  // wide rows (tree node ids) are swept in column chunks
-    auto kern = s.formula == 0 ? (chunked ? exact_scan_kernel<0, true> : exact_scan_kernel<0, false>)
-              : s.formula == 1 ? (chunked ? exact_scan_kernel<1, true> : exact_scan_kernel<1, false>)
-                               : (chunked ? exact_scan_kernel<2, true> : exact_scan_kernel<2, false>);
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    kern<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
-    HIP_TRY(hipGetLastError());
-    return SKNNR_OK;
+    switch (s.formula) {
+        case 0: return launch_scan_formula<0>(ix, a, max_items, chunked, sh, st);
+        case 1: return launch_scan_formula<1>(ix, a, max_items, chunked, sh, st);
+        default: return launch_scan_formula<2>(ix, a, max_items, chunked, sh, st);
+    }
 }
 
 struct CallCtx {
