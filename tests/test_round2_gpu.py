@@ -423,3 +423,41 @@ def test_adversarial_operands_end_to_end_on_the_second_kernel(N, O, d, law):
     st = ix.stats()
     assert st["coarse_queries"] == nq, st  # the MFMA path answered (no whole-call exact scan)
     ix.close()
+
+
+@pytest.mark.parametrize("formula", ["expanded", "direct"])
+@pytest.mark.parametrize("deterministic", [True, False])
+@pytest.mark.parametrize("kind", ["smooth", "integer", "duplicates"])
+def test_sliced_exact_scan_small_calls(N, O, formula, deterministic, kind):
+    """Calls with few rows split the reference rows of a scan pass over several workgroups and merge the slice
+    heaps (exact.hip.h, scan_merge_kernel).  d = 200 keeps the MFMA pre-filter out: every row is answered by the
+    scan.  Integer-valued features and duplicated reference rows make exact ties at the k-th distance the norm: the
+    merge must recognise that the reference's heap decides those by its history and hand them to the sequential
+    scan.  X=None adds the drop-self rule."""
+    rng = np.random.default_rng(77)
+    n_ref, nq, d, k = 3000, 40, 200, 5
+    x_ref = rng.standard_normal((n_ref, d))
+    x_q = rng.standard_normal((nq, d))
+    if kind == "integer":
+        x_ref, x_q = np.round(x_ref[:, :8] * 1.5), np.round(x_q[:, :8] * 1.5)
+        x_ref = np.concatenate([x_ref, np.zeros((n_ref, d - 8))], axis=1)
+        x_q = np.concatenate([x_q, np.zeros((nq, d - 8))], axis=1)
+    elif kind == "duplicates":
+        x_ref[1500:1540] = x_ref[100:140]      # copies far apart in index: different slices
+        x_ref[2900:2910] = x_ref[100:110]
+        x_q[:20] = x_ref[100:120] + 1e-9
+    ix = N.Index(x_ref)
+    fcode = N.FORMULA_EXPANDED if formula == "expanded" else N.FORMULA_DIRECT
+    dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k, formula=fcode, deterministic=deterministic))
+    od, oi = O.kneighbors(x_ref, x_q, k, formula, deterministic=deterministic)
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(dist, od)
+    st = ix.stats()
+    assert st["exact_only_queries"] == nq
+    # X=None on a slice of the reference rows (global row offset 90: rows 90..149 include duplicated ones)
+    dist, idx = ix.kneighbors_host(None, ix.make_opts(k, formula=fcode, deterministic=deterministic, exclude_self=True,
+                                                       row_offset=90), nq=60)
+    od, oi = O.kneighbors(x_ref, None, k, formula, deterministic=deterministic)
+    np.testing.assert_array_equal(idx, oi[90:150])
+    np.testing.assert_array_equal(dist, od[90:150])
+    ix.close()
