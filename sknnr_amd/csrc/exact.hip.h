@@ -483,6 +483,22 @@ __device__ __forceinline__ int group_min_i(int v, int c) {
     }
 }
 
+// value of the lane that names `dst_lane` (a lane of this wave) as its destination; every destination is named once
+template <int LPQ>
+__device__ __forceinline__ double scatter_d(double v, int dst_lane) {
+    const long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_permute(dst_lane << 2, (int)(unsigned)(unsigned long)bits);
+    const int hi = __builtin_amdgcn_ds_permute(dst_lane << 2, (int)((unsigned long)bits >> 32));
+    return __longlong_as_double((long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo));
+}
+// does any lane of the group starting at wave lane `gbase` hold the flag?
+template <int LPQ>
+__device__ __forceinline__ bool group_any(bool flag, int gbase) {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(flag);
+    const unsigned long long mask = LPQ == 64 ? ~0ull : (((1ull << (LPQ & 63)) - 1ull) << gbase);
+    return (b & mask) != 0ull;
+}
+
 // (measured: forcing 8 waves per SIMD on the 12-candidate instantiation -- 64 VGPRs, 68 bytes of scratch -- takes 8.0 ms
 // instead of 4.5 ms per 10M rows; the compiler's 80 VGPRs / 6 waves stay)
 template <int M>
@@ -526,7 +542,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const bool need = valid && ((double)cv <= tau_c + 2.0 * eps + 2.0 * noise * a.s2);
 
     double d2 = INFINITY;
+#ifdef SKNNR_ABLATE_FIN_SAMEROW  // timing experiment: every lane gathers a row next to its query's first candidate
+    if (need) d2 = pair_d2(s.xq + q * s.d, s.ref + (long)(__shfl(id, 0, LPQ) & 0xffff) * s.d, s.d, s.rn[id], s.formula) + id * 1e-30;
+#else
     if (need) d2 = pair_d2(s.xq + q * s.d, s.ref + (long)id * s.d, s.d, s.rn[id], s.formula);
+#endif
     const bool usable = need && (d2 == d2) && d2 < INFINITY;
     if (!usable) d2 = INFINITY;
     const int key_id = usable ? id : (0x7fffff00 + c);  // unusable slots sort last, distinct
@@ -559,18 +579,16 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     // Exactly tied float64 distances: which tied row the reference keeps at the k-th slot (and,
     // without deterministic ordering, in which order it lists tied rows) depends on its heap's
     // history -- such queries are replayed by exact_scan_kernel.
+    // (values scattered to their rank's lane: a tie involves two neighbours of that order.  d2 is ascending in the
+    //  rank, unusable slots hold +inf at the end.)
     {
-        const bool mine = usable && (rank < s.kk);
-        int ties = 0;
-        const PeersI<LPQ> rank_of(rank);
-        for_each_peer<LPQ>([&](auto n) {
-            const double dj = d2_of.template get<n.value>();
-            const int rj = rank_of.template get<n.value>();
-            if (s.deterministic) ties += (dj == d2) && mine && (rj >= s.kk);  // tie across the boundary
-            else ties += (dj == d2) && mine;                                    // any tie involving a kept row
-        });
-        const int any_tie = group_min_i<LPQ>(-ties, c);
-        if (any_tie < 0) certified = false;
+        const int gbase = (int)(threadIdx.x & 63) & ~(LPQ - 1);
+        const double by_rank = scatter_d<LPQ>(d2, gbase + rank);          // lane r of the group: the r-th smallest d2
+        const double next = __shfl_down(by_rank, 1, LPQ);                // lane r: the (r+1)-th smallest (r = LPQ-1: itself)
+        const bool has_next = c + 1 < LPQ;
+        const bool tied_here = has_next && by_rank == next && by_rank < INFINITY &&
+                               (s.deterministic ? c == s.kk - 1 : c < s.kk);  // across the boundary / involving a kept row
+        if (group_any<LPQ>(tied_here, gbase)) certified = false;
     }
 
     // X=None: drop the row's own index, or the first entry when it is absent
@@ -588,31 +606,44 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 
     int pos = sel;
     if (s.deterministic) {
-        // REF/src/sknnr/_base.py:166-175
+        // REF/src/sknnr/_base.py:166-175.  The rounded keys are non-decreasing in `sel`; only equal neighbours can
+        // change places, and that is rare (distances equal to 10 decimals): the all-pairs ordering below runs only in
+        // waves that hold such a pair.
         const double dmax = group_max<LPQ>(chosen ? dist : 0.0, c);
         const double row_scale = fmax(dmax, 1.0);
         const double k0 = chosen ? round_key(dist / row_scale, s.pow10, s.pow10_is_divisor) : INFINITY;
-        long k1 = (long)id - self_id;
-        k1 = k1 < 0 ? -k1 : k1;
-        const int tagged = key_id | (chosen ? (int)0x80000000u : 0);  // key_id >= 0: bit 31 carries `chosen`
-        pos = 0;
-        const PeersD<LPQ> k0_of(k0);
-        const PeersL<LPQ> k1_of(k1);
-        const PeersI<LPQ> tag_of(tagged);
-        for_each_peer<LPQ>([&](auto n) {
-            const double k0j = k0_of.template get<n.value>();
-            const long k1j = k1_of.template get<n.value>();
-            const int tj = tag_of.template get<n.value>();
-            const int ij = tj & 0x7fffffff;
-            const bool less = (k0j < k0) || (k0j == k0 && (k1j < k1 || (k1j == k1 && ij < key_id)));
-            pos += (tj < 0) && less;
-        });
+        const int gbase = (int)(threadIdx.x & 63) & ~(LPQ - 1);
+        // slot `sel` of the group for every lane that has one (unique: 0 .. LPQ-2 after a drop), the dropped lane parks at the end
+        const double k0_by_sel = scatter_d<LPQ>(k0, gbase + (sel >= 0 ? sel : LPQ - 1));
+        const double k0_next = __shfl_down(k0_by_sel, 1, LPQ);
+        const bool equal_keys = c + 1 < s.k && c + 1 < LPQ && k0_by_sel == k0_next && k0_by_sel < INFINITY;
+        if (__builtin_amdgcn_ballot_w64(equal_keys) != 0) {
+            long k1 = (long)id - self_id;
+            k1 = k1 < 0 ? -k1 : k1;
+            const int tagged = key_id | (chosen ? (int)0x80000000u : 0);  // key_id >= 0: bit 31 carries `chosen`
+            pos = 0;
+            const PeersD<LPQ> k0_of(k0);
+            const PeersL<LPQ> k1_of(k1);
+            const PeersI<LPQ> tag_of(tagged);
+            for_each_peer<LPQ>([&](auto n) {
+                const double k0j = k0_of.template get<n.value>();
+                const long k1j = k1_of.template get<n.value>();
+                const int tj = tag_of.template get<n.value>();
+                const int ij = tj & 0x7fffffff;
+                const bool less = (k0j < k0) || (k0j == k0 && (k1j < k1 || (k1j == k1 && ij < key_id)));
+                pos += (tj < 0) && less;
+            });
+        }
     }
     if (live && chosen) {
         if (s.out_dist) s.out_dist[q * s.k + pos] = dist;
         s.out_idx[q * s.k + pos] = id;
     }
+#ifdef SKNNR_ABLATE_FIN_SAMEROW
+    if (live && c == 0 && !certified && q < 0) {
+#else
     if (live && c == 0 && !certified) {
+#endif
         const int slot = atomicAdd(a.fail_count, 1);
         a.fail_list[slot] = a.fail_base + (int)q;
     }
