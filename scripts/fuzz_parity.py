@@ -31,6 +31,35 @@ while time.time() < t_end:
         d = int(rng.choice([8, 16, 32, 64]))
     kmax = min(n_ref, 34)
     k = int(rng.integers(1, kmax + 1))
+    if not big and rng.integers(0, 6) == 0:
+        # RFNN / GBNN: weighted Hamming distance over node-id columns (few distinct ids: exact ties are the norm),
+        # uniform or random weights, both orderings, X=None; wide matrices take the column-chunked sweep
+        t = int(rng.choice([1, 7, 64, 300, 1100]))
+        ids_ref = rng.integers(0, int(rng.choice([2, 5, 40])), (max(n_ref, 2), t)).astype(np.float64)[:n_ref]
+        ids_q = rng.integers(0, 40, (nq, t)).astype(np.float64)
+        ids_q[: nq // 2] = ids_ref[rng.integers(0, n_ref, nq // 2)]  # half of the queries sit on reference rows
+        w = np.full(t, 1.0 / t) if rng.integers(0, 2) else rng.random(t) + 0.01
+        det = bool(rng.integers(0, 2))
+        hx = N.Index(ids_ref)
+        try:
+            hx.set_hamming_weights(w)
+            if rng.integers(0, 4) == 0 and k < n_ref:
+                dist, idx = hx.kneighbors_host(None, hx.make_opts(k, exclude_self=True, deterministic=det,
+                                                                  formula=N.FORMULA_HAMMING), nq=n_ref)
+                od, oi = O.kneighbors_hamming(ids_ref, None, w, k, deterministic=det)
+            else:
+                off = int(rng.choice([0, 17]))
+                dist, idx = hx.kneighbors_host(ids_q, hx.make_opts(k, deterministic=det, formula=N.FORMULA_HAMMING,
+                                                                   row_offset=off))
+                od, oi = O.kneighbors_hamming(ids_ref, ids_q, w, k, deterministic=det, row_offset=off)
+            if not (np.array_equal(idx, oi) and np.array_equal(dist, od)):
+                print(f"HAMMING MISMATCH n_ref={n_ref} nq={nq} trees={t} k={k} det={det} seed={seed}")
+                sys.exit(1)
+        finally:
+            hx.close()
+        n_cases += 1
+        n_rows += nq
+        continue
     kind = rng.choice(["smooth", "dup", "integer", "tiny_scale", "huge_offset", "huge_offset", "far_queries"])
     x_ref, _, x_q = synth.make_problem(max(n_ref, 2), nq, d, t=1, n_dup_refs=min(n_ref // 3, 40) if kind == "dup" else 0,
                                        n_dup_queries=min(nq // 3, 30, max(n_ref, 2) // 2) if kind == "dup" else 0)
