@@ -183,7 +183,7 @@ def mfma_frac(nq, n_ref, d_t, coarse_ms):
 
 
 def extra_config(name, kind, nq, n_ref, d_in, k, torch, device, *, t=40, n_components=None, predict=None,
-                 dataframe_ids=False, law="baseline", x_ref=None, check_rows=2048):
+                 dataframe_ids=False, law="baseline", x_ref=None, check_rows=100_000):
     """One BASELINE configuration on one GPU, device-resident input: wall and kernel time, roofline
     fraction of its pre-filter, and a slice checked against the oracle."""
     eng, x_ref_t, affine, y, fit_s = fit_space(kind, n_ref, d_in, t, device, n_components, x_ref=x_ref)
