@@ -491,6 +491,13 @@ __device__ __forceinline__ double scatter_d(double v, int dst_lane) {
     const int hi = __builtin_amdgcn_ds_permute(dst_lane << 2, (int)((unsigned long)bits >> 32));
     return __longlong_as_double((long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo));
 }
+// number of lanes of the group starting at wave lane `gbase` that hold the flag
+template <int LPQ>
+__device__ __forceinline__ int group_count(bool flag, int gbase) {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(flag);
+    const unsigned long long mask = LPQ == 64 ? ~0ull : (((1ull << (LPQ & 63)) - 1ull) << gbase);
+    return __builtin_popcountll(b & mask);
+}
 // does any lane of the group starting at wave lane `gbase` hold the flag?
 template <int LPQ>
 __device__ __forceinline__ bool group_any(bool flag, int gbase) {
@@ -526,15 +533,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const double nrm = sqrt(qn) + a.ymax;
     const double eps = a.eps_c * nrm * nrm;
     const float cve = valid ? cv : INFINITY;
-    int rank_c = 0;
-    const PeersI<LPQ> lane_of(c);
+    // the kk-th smallest pre-filter value of the group: the smallest value that at least kk values do not exceed
+    int n_le = 1;
     const PeersF<LPQ> cve_of(cve);
-    for_each_peer<LPQ>([&](auto n) {
-        const float cj = cve_of.template get<n.value>();
-        const int pj = lane_of.template get<n.value>();
-        rank_c += (cj < cve) || (cj == cve && pj < c);
-    });
-    const double tau_c = group_min<LPQ>(rank_c >= s.kk - 1 ? (double)cve : INFINITY, c);
+    for_each_peer<LPQ>([&](auto n) { n_le += cve_of.template get<n.value>() <= cve; });
+    const double tau_c = group_min<LPQ>(n_le >= s.kk ? (double)cve : INFINITY, c);
     // ... and the reference ranks by its rounded float64 expression: two rows closer than twice its noise
     // may come out in either order, so the window widens by that much (in scaled units).
     const double nr = nrm * a.inv_s + a.mu2;
@@ -552,15 +555,15 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const int key_id = usable ? id : (0x7fffff00 + c);  // unusable slots sort last, distinct
 
     // rank by (d2, index)
-    int rank = 0, n_usable = usable ? 1 : 0;
+    int rank = 0;
     const PeersD<LPQ> d2_of(d2);
     const PeersI<LPQ> key_of(key_id);
     for_each_peer<LPQ>([&](auto n) {
         const double dj = d2_of.template get<n.value>();
         const int ij = key_of.template get<n.value>();
         rank += (dj < d2) || (dj == d2 && ij < key_id);
-        n_usable += dj < INFINITY;
     });
+    const int n_usable = group_count<LPQ>(usable, (int)(threadIdx.x & 63) & ~(LPQ - 1));
 
     // certificate: every reference outside the lists has a float64 d2 above tau
     const double tau = group_min<LPQ>(rank >= s.kk - 1 ? d2 : INFINITY, c);
