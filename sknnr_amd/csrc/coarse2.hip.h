@@ -1,4 +1,5 @@
-// coarse2.hip.h -- second-generation MFMA pre-filter for feature spaces up to 64 wide (KS <= 4, lists of 6 / 8).
+// coarse2.hip.h -- second-generation MFMA pre-filter for feature spaces up to 64 wide (KS <= 4, lists of 6 / 8:
+// n_neighbors 2 .. 7 searched; coarse2_supported).
 //
 // Same contract as coarse_kernel (coarse.hip.h): for every query, the M smallest ranking values
 //   v(q, r) ~= |r'|^2 - 2 q'.r'   seen by each of the two lanes that own the query, with the J-th
@@ -7,11 +8,13 @@
 //
 //   * On gfx950 a wave's VALU instructions overlap an MFMA only when they do not depend on it and sit
 //     behind it in the SAME wave's stream (about four per 32x32x16 MFMA are free; VALU of another wave
-//     of the SIMD is not overlapped, whatever the wave priorities).  The sweep is therefore software
-//     pipelined inside the wave: the main products of unit u+1 (a unit = one 32-reference tile x one
-//     32-query block) are issued first, then the skip test of unit u runs in their shadow.  The |r'|^2
-//     C operand is read from LDS straight into the accumulator registers, which pays for the second
-//     accumulator set.
+//     of the SIMD is not overlapped, whatever the wave priorities).  The sweep is therefore scheduled by
+//     hand inside the wave, tile by tile (a unit = one 32-reference tile x one 32-query block, two units
+//     per tile): the main products of both units go out back to back and the skip test of the first unit
+//     sits behind the MFMAs of the second (tile_issue_and_test).  The |r'|^2 C operand is read from LDS
+//     straight into the accumulator registers, which pays for the second accumulator set.  (Pipelining
+//     across tiles -- the products of unit u+1 before the test of unit u -- exposes one LDS wait per unit
+//     and measured slower: DESIGN.md section 4.2.)
 //   * The two correction products (lo.hi + hi.lo, four MFMAs per visited unit) are gone from the sweep.
 //     A unit is visited when some value's MAIN product is below threshold + margin (margin >= the size of
 //     the correction, as before); such values are queued with their main value, and the batched flush
@@ -22,8 +25,10 @@
 //   * LDS stages hold only hi fragments + |r'|^2 (16 tiles per stage: half the barriers).
 //   * Seeding: the first kSeedTiles tiles are swept once with a one-insertion-per-unit rule (each lane
 //     inserts its smallest main value) to obtain a valid starting threshold (J-th smallest seed value +
-//     margin); the real sweep then starts with a tight threshold instead of taking ~1000 hits per
+//     2 x margin); the real sweep then starts with a tight threshold instead of taking ~1000 hits per
 //     q-block in the first tiles.
+//   * WAVES = 16 for the bulk of a call, 4 for the rows of a thin last round and for small calls (host side:
+//     launch_coarse2_ks).
 #pragma once
 #include "coarse.hip.h"
 
@@ -64,16 +69,16 @@ __device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc)
     return acc;
 }
 
-// One pipelined step, hand scheduled (hipcc neither interleaves independent VALU work between dependent
-// MFMAs nor sees through the raw min instructions): the KS main MFMAs of the NEXT unit go out with the min
-// tree of the PREVIOUS unit's sixteen values placed behind them, about four VALU instructions per MFMA --
-// what the matrix pipe covers (scripts/microbench/mfma_shadow.hip).
-//   y        : accumulator of the next unit, holds |r'|^2 on entry (C operand in place)
-//   x[0..15] : main products of the previous unit (their MFMAs were issued one step ago)
+// The skip test of a unit: the minimum of its sixteen main values, as raw instructions (hipcc neither interleaves
+// independent VALU work between dependent MFMAs nor sees through the min instructions, so the tile step below is
+// written out in asm: MFMAs back to back, the tree of the first unit behind the MFMAs of the second -- about four
+// VALU instructions per MFMA are what the matrix pipe covers, scripts/microbench/mfma_shadow.hip).
+//   x[0..15] : main products of the unit
 //   g[0..4]  : minima of {0-2}, {3-5}, {6-8}, {9-11}, {12-15};  m: minimum of all sixteen
-// Hazard (guide section 5.7): a VALU read of an MFMA result needs 11 wait states after the 8-pass MFMA was
-// issued and nothing pads the inside of an asm statement.  The second MFMA of the previous step was followed
-// by at least 6 VALU instructions of that step; `s_nop 4` supplies the remaining 5.
+// Hazard (guide section 5.7): a VALU read of an MFMA result needs 11 wait states after the 8-pass MFMA was issued,
+// and nothing pads the inside of an asm statement: every tree is preceded by explicit s_nop padding that covers
+// the distance to the last MFMA writing its inputs (11 states in tile_issue_and_test, where one independent MFMA
+// sits in between; 16 in step_test_only, where the unit's last MFMA was the previous instruction).
 #define SKNNR_TREE_A                                   \
     "v_min3_f32 %[g0], %[x0], %[x1], %[x2]\n\t"        \
     "v_min3_f32 %[g1], %[x3], %[x4], %[x5]\n\t"        \
