@@ -237,6 +237,30 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
                                             use_deterministic_ordering=use_deterministic_ordering)
         return self._finish_kneighbors(dist, idx, return_distance, return_dataframe_index)
 
+    def kneighbors_graph(self, X=None, n_neighbors=None, mode="connectivity"):
+        """Sparse (n_queries, n_samples_fit) graph of the k neighbours of every row: ones, or the distances
+        with ``mode="distance"`` -- the method the reference's estimator inherits from scikit-learn
+        (SKL/neighbors/_base.py, KNeighborsMixin.kneighbors_graph), over this class's ``kneighbors``."""
+        from scipy.sparse import csr_matrix
+
+        check_is_fitted(self, "_fit_X")
+        k = self._resolve_k(n_neighbors)
+        if mode == "connectivity":
+            ind = self.kneighbors(X, k, return_distance=False)
+            ind = ind.cpu().numpy() if is_torch_cuda_tensor(ind) else ind
+            data = np.ones(ind.shape[0] * k)
+        elif mode == "distance":
+            data, ind = self.kneighbors(X, k, return_distance=True)
+            if is_torch_cuda_tensor(ind):
+                data, ind = data.cpu().numpy(), ind.cpu().numpy()
+            data = np.ravel(data)
+        else:
+            raise ValueError(
+                f'Unsupported mode, must be one of "connectivity", or "distance" but got "{mode}" instead')
+        n_queries = ind.shape[0]
+        indptr = np.arange(0, n_queries * k + 1, k)
+        return csr_matrix((data, ind.ravel(), indptr), shape=(n_queries, self.n_samples_fit_))
+
     def _finish_kneighbors(self, dist, idx, return_distance, return_dataframe_index):
         if return_dataframe_index:
             msg = "Dataframe indexes can only be returned when fitted with a dataframe."

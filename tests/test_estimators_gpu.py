@@ -305,3 +305,23 @@ def test_sharded_single_rank_over_rccl(E, moscow):
             np.testing.assert_array_equal(cd.cpu().numpy(), want_d)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["connectivity", "distance"])
+def test_kneighbors_graph(E, moscow, mode):
+    """The graph method scikit-learn's KNeighborsMixin gives the reference's RawKNNRegressor: CSR rows of the k
+    neighbours (ones or distances), X=None excluding each row itself; an unknown mode raises scikit-learn's sentence."""
+    from oracle import oracle as O
+
+    X, y = moscow["X_train"], moscow["y_train"]
+    est = E.RawKNNRegressor(n_neighbors=4).fit(X, y)
+    for query, want in ((moscow["X_test"], O.kneighbors(X, moscow["X_test"], 4)), (None, O.kneighbors(X, None, 4))):
+        g = est.kneighbors_graph(query, mode=mode)
+        od, oi = want
+        assert g.shape == (len(oi), len(X)) and g.nnz == oi.size
+        dense = np.zeros(g.shape)
+        np.put_along_axis(dense, oi, np.ones_like(od) if mode == "connectivity" else od, axis=1)
+        np.testing.assert_array_equal(g.toarray(), dense)
+    assert est.kneighbors_graph(moscow["X_test"], n_neighbors=2).nnz == 2 * len(moscow["X_test"])
+    with pytest.raises(ValueError, match="Unsupported mode"):
+        est.kneighbors_graph(moscow["X_test"], mode="nope")
