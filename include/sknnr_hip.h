@@ -239,8 +239,9 @@ int sknnr_predict_from_neighbors(sknnr_index* index, const double* dist, const i
  *           calls on the handle fail while it is open (device-memory calls are allowed).
  *   push  : q is a HOST (nq, d_in or d) tile and may be reused as soon as the call returns.  The
  *           tile's results are written to the HOST buffers passed with it -- out_idx (nq, k), out_dist
- *           (nq, k) or NULL, out_pred (nq, t) or NULL -- at the latest when the second-next push, a
- *           flush or end returns; the buffers must stay valid until then.
+ *           (nq, k) or NULL, out_pred (nq, t) or NULL -- at the latest when a flush or end returns (earlier in
+ *           practice: a tile leaves its pipeline slot when the slot is needed again, four tiles later);
+ *           the buffers must stay valid until then.
  *   flush : every pushed tile's results are in place on return.  With opts->check_finite the status
  *           is SKNNR_ERR_NONFINITE if any pushed value was NaN or infinite.
  *   end   : flush, then free the stream (NULL is allowed); *rows_pushed (optional) = total rows.
@@ -266,7 +267,8 @@ int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int64_t* idx, i
 /*
  * Full matrix of the pre-filter's approximate ranking values for a small problem:
  *   out[i, j] ~= s^2 (|r_j - mu|^2 - 2 (q_i - mu).(r_j - mu))   float32, host (nq, n_ref)
- * computed by the same MFMA sequence as the production kernel.  Also returns the scale s,
+ * computed by the MFMA sequence of the first-generation kernel (all three split products on the matrix pipe;
+ * the second-generation kernel's values differ by its smaller rounding budget only and are covered end to end).  Also returns the scale s,
  * the per-query |s (q_i - mu)|^2 (host, nq) and the error budget eps the certificate uses.
  * q is host, already transformed (d columns).  nq * n_ref must be <= 2^24.
  */
