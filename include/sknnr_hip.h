@@ -245,6 +245,7 @@ int sknnr_predict_from_neighbors(sknnr_index* index, const double* dist, const i
  *   flush : every pushed tile's results are in place on return.  With opts->check_finite the status
  *           is SKNNR_ERR_NONFINITE if any pushed value was NaN or infinite.
  *   end   : flush, then free the stream (NULL is allowed); *rows_pushed (optional) = total rows.
+ * A stream refers to its index: end it before sknnr_index_destroy.
  */
 typedef struct sknnr_stream sknnr_stream;
 int sknnr_stream_begin(sknnr_index* index, const sknnr_query_opts* opts, int32_t want_dist, int32_t want_pred,
