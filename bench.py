@@ -177,6 +177,15 @@ def cpu_reference(x_ref_t, affine, q_raw_sample, k, algorithm="auto"):
         return info, (dist, idx)
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (the file travels with the repository)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as fh:
+            return json.load(fh)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "Mqueries/sec + achieved HBM GB/s, 10M\u00d750k\u00d732 k=5, 1/2/4/8 MI355X"
+
+
 def mfma_frac(nq, n_ref, d_t, coarse_ms):
     tf = 2.0 * nq * n_ref * d_t / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
     return tf, tf / PEAK_F16_MFMA_TFLOPS
@@ -366,7 +375,7 @@ def main():
             "hbm_frac_of_peak": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
         }
         result = {
-            "metric": "Mqueries/sec + achieved HBM GB/s, 10M x 50k x 32 k=5, 1/2/4/8 MI355X",
+            "metric": baseline_metric(),
             "value": value, "unit": "Mqueries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f16 split MFMA (hi.hi swept, lo.hi + hi.lo corrections; f32 accumulate) pre-filter + f64 exact re-score",
