@@ -506,8 +506,9 @@ __device__ __forceinline__ bool group_any(bool flag, int gbase) {
     return (b & mask) != 0ull;
 }
 
-// (measured: forcing 8 waves per SIMD on the 12-candidate instantiation -- 64 VGPRs, 68 bytes of scratch -- takes 8.0 ms
-// instead of 4.5 ms per 10M rows; the compiler's 80 VGPRs / 6 waves stay)
+// (measured per 10M rows: forcing 8 waves per SIMD on the 12-candidate instantiation -- 64 VGPRs, 68 bytes of scratch --
+// takes 8.0 ms instead of 4.5; collapsing the row gathers to one row per query saves 0.3 ms; dropping the index
+// tie-break from the ranking loop saves nothing: the compiler's 80 VGPRs / 6 waves stay)
 template <int M>
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     constexpr int LPQ = 2 * M;
@@ -545,11 +546,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const bool need = valid && ((double)cv <= tau_c + 2.0 * eps + 2.0 * noise * a.s2);
 
     double d2 = INFINITY;
-#ifdef SKNNR_ABLATE_FIN_SAMEROW  // timing experiment: every lane gathers a row next to its query's first candidate
-    if (need) d2 = pair_d2(s.xq + q * s.d, s.ref + (long)(__shfl(id, 0, LPQ) & 0xffff) * s.d, s.d, s.rn[id], s.formula) + id * 1e-30;
-#else
     if (need) d2 = pair_d2(s.xq + q * s.d, s.ref + (long)id * s.d, s.d, s.rn[id], s.formula);
-#endif
     const bool usable = need && (d2 == d2) && d2 < INFINITY;
     if (!usable) d2 = INFINITY;
     const int key_id = usable ? id : (0x7fffff00 + c);  // unusable slots sort last, distinct
@@ -642,11 +639,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         if (s.out_dist) s.out_dist[q * s.k + pos] = dist;
         s.out_idx[q * s.k + pos] = id;
     }
-#ifdef SKNNR_ABLATE_FIN_SAMEROW
-    if (live && c == 0 && !certified && q < 0) {
-#else
     if (live && c == 0 && !certified) {
-#endif
         const int slot = atomicAdd(a.fail_count, 1);
         a.fail_list[slot] = a.fail_base + (int)q;
     }
