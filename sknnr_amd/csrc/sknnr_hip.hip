@@ -220,6 +220,12 @@ struct sknnr_index {
     // ev_ws; the next call's stream waits for it before it touches the workspace.
     hipEvent_t ev_ws = nullptr;
     bool ws_busy = false;
+    // The thin last round of the pre-filter (4-wave workgroups, one wave per SIMD) leaves most of every CU free: the
+    // finaliser of the rows that are already done runs beside it on a side stream (fork after the bulk launch, join
+    // before the exact scan).
+    hipStream_t st_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    long bulk_rows_done = 0;  // rows whose pre-filter was complete at ev_fork (0: no fork in the last launch)
     bool stream_open = false;  // a sknnr_stream owns the host pipeline's slots
 
     // Device timing of calls (HIP events on the launch stream), resolved lazily by sknnr_get_stats:
@@ -260,6 +266,9 @@ struct sknnr_index {
         for (hipStream_t h : {st_h2d, st_run, st_d2h})
             if (h) (void)hipStreamDestroy(h);
         if (ev_ws) (void)hipEventDestroy(ev_ws);
+        if (st_side) (void)hipStreamDestroy(st_side);
+        for (hipEvent_t e : {ev_fork, ev_join})
+            if (e) (void)hipEventDestroy(e);
         for (auto& ct : timing) {
             for (hipEvent_t e : {ct.e0, ct.e1})
                 if (e) (void)hipEventDestroy(e);
@@ -976,9 +985,14 @@ int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
     long tail_wg = n_wg % kCusPerDevice;
     if (!split || tail_wg > kCusPerDevice / (kCoarse2Waves / kCoarse2TailWaves)) tail_wg = 0;
     const long bulk_rows = (n_wg - tail_wg) * QPB;
+    ix->bulk_rows_done = 0;
     if (bulk_rows > 0) {
         int rc = launch_coarse2_waves<KS, M, kCoarse2Waves>(ix, 0, bulk_rows, kk, st);
         if (rc) return rc;
+        if (tail_wg > 0 && ix->ev_fork) {  // the caller finalises these rows beside the thin round
+            HIP_TRY(hipEventRecord(ix->ev_fork, st));
+            ix->bulk_rows_done = bulk_rows;
+        }
     }
     if (tail_wg > 0) return launch_coarse2_waves<KS, M, kCoarse2TailWaves>(ix, bulk_rows, tail_wg * QPB, kk, st);
     return SKNNR_OK;
@@ -1263,6 +1277,12 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         auto& ev = ct.coarse[ct.coarse_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
         const bool v2 = use_coarse2(ix, coarse_list_len(kk));
+        if (v2 && !ix->st_side && !std::getenv("SKNNR_NO_SIDE_STREAM")) {
+            HIP_TRY(hipStreamCreateWithFlags(&ix->st_side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
+        }
+        ix->bulk_rows_done = 0;
         int rc = v2 ? launch_coarse2(ix, n_pad, coarse_list_len(kk), kk, st)
                     : launch_coarse(ix, n_pad, coarse_list_len(kk), kk, st);
         if (rc) return rc;
@@ -1290,8 +1310,34 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         f.fail_list = ix->fail_list.p;
         f.fail_count = ix->fail_count.p;
         f.fail_base = (int)c0;
-        launch_finalize(f, n, st);
-        HIP_TRY(hipGetLastError());
+        // rows [r0, r0 + rows) of the chunk (the kernel indexes everything by the row inside its window)
+        auto finalize_rows = [&](long r0, long rows, hipStream_t s_) {
+            FinalizeArgs g = f;
+            g.s.xq = f.s.xq + r0 * ix->d;
+            g.s.nq = rows;
+            g.s.row_offset = f.s.row_offset + r0;
+            g.s.out_dist = f.s.out_dist ? f.s.out_dist + r0 * o->n_neighbors : nullptr;
+            g.s.out_idx = f.s.out_idx + r0 * o->n_neighbors;
+            g.cand_val = f.cand_val + (size_t)r0 * 2 * f.m_list;
+            g.cand_idx = f.cand_idx + (size_t)r0 * 2 * f.m_list;
+            g.qnc = f.qnc + r0;
+            g.fail_base = f.fail_base + (int)r0;
+            launch_finalize(g, rows, s_);
+        };
+        const long done = v2 ? std::min<long>(ix->bulk_rows_done, n) : 0;
+        if (done > 0) {
+            // fork: the rows of the bulk launch are finalised on the side stream while the thin round runs here
+            HIP_TRY(hipStreamWaitEvent(ix->st_side, ix->ev_fork, 0));
+            finalize_rows(0, done, ix->st_side);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ix->ev_join, ix->st_side));
+            if (n > done) finalize_rows(done, n - done, st);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamWaitEvent(st, ix->ev_join, 0));  // join before anything else touches the workspace
+        } else {
+            finalize_rows(0, n, st);
+            HIP_TRY(hipGetLastError());
+        }
     }
     // One exact scan per call: the rows the finaliser could not certify (call-relative ids), or
     // every row when the call is outside the MFMA envelope.

@@ -461,3 +461,32 @@ def test_sliced_exact_scan_small_calls(N, O, formula, deterministic, kind):
     np.testing.assert_array_equal(idx, oi[90:150])
     np.testing.assert_array_equal(dist, od[90:150])
     ix.close()
+
+
+def test_thin_round_with_the_finaliser_on_the_side_stream(N, O):
+    """256 + 20 workgroups' worth of rows: the bulk launch fills one round of the device, the remaining rows
+    run on 4-wave workgroups while the finaliser of the bulk rows works beside them on the handle's side stream
+    (fork / join by events).  Every row -- bulk, thin round, and the uncertified ones collected from both
+    finalisers -- must equal the oracle, on the caller's stream and on the host pipeline."""
+    import torch
+
+    from sknnr_amd import synth
+
+    nq = (256 + 20) * 1024 - 77
+    x_ref, _, x_q = synth.make_problem(6000, nq, 16, t=1)
+    ix = N.Index(x_ref)
+    o = ix.make_opts(5, row_offset=1000)
+    qd = torch.as_tensor(x_q, device="cuda")
+    dd = torch.empty((nq, 5), dtype=torch.float64, device="cuda")
+    di = torch.empty((nq, 5), dtype=torch.int64, device="cuda")
+    od, oi = O.kneighbors(x_ref, x_q, 5, "expanded", row_offset=1000)
+    for _ in range(3):  # repeated: the fork/join must also order consecutive calls on the shared workspace
+        dd.zero_()
+        di.zero_()
+        ix.kneighbors_device(qd.data_ptr(), nq, o, dd.data_ptr(), di.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(di.cpu().numpy(), oi)
+        np.testing.assert_array_equal(dd.cpu().numpy(), od)
+    st = ix.stats()
+    assert st["exact_fallbacks"] > 0 and st["coarse_queries"] == 3 * nq
+    ix.close()
