@@ -216,7 +216,8 @@ def extra_config(name, kind, nq, n_ref, d_in, k, torch, device, *, t=40, n_compo
     st = eng.stats()
     coarse_ms = st["total_coarse_ms"] / max(1, st["timed_calls"])
     kernel_ms = st["total_kernel_ms"] / max(1, st["timed_calls"])
-    tf, frac = mfma_frac(nq, n_ref, d_t, coarse_ms)
+    # (rows the timed pre-filter launches processed: the thin last round that runs beside the finaliser is not timed)
+    tf, frac = mfma_frac(st["coarse_rows_timed"] / max(1, st["timed_calls"]), n_ref, d_t, coarse_ms)
     n_chk = min(check_rows, nq)
     q_host = q[:n_chk].cpu().numpy()
     if predict:
@@ -348,7 +349,10 @@ def main():
     value = total_rows * args.steps / elapsed / 1e6
 
     if rank == 0:
-        achieved_tf, frac = mfma_frac(nq, args.refs, d_t, coarse_ms)  # this rank's rows through this rank's kernel
+        # this rank's rows through this rank's kernel: the rows of the launches that coarse_ms sums (when the thin last
+        # round of a call runs beside the finaliser, only the 16-wave bulk launch is timed, and only its rows are priced)
+        rows_timed = st["coarse_rows_timed"] / args.steps
+        achieved_tf, frac = mfma_frac(rows_timed, args.refs, d_t, coarse_ms)
         alg_bytes = nq * args.dims * 8 + args.refs * d_t * 8 + nq * k * 16
         traffic, traffic_note = None, None
         for pmc_name in ("r02_coarse_pmc.json", "r01_coarse_pmc.json"):
@@ -358,18 +362,19 @@ def main():
                 # passes of this same command give HBM bytes per query row for the dominant kernel
                 # (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section), scaled to this step.
                 pmc = json.load(open(pmc_file))
-                traffic = pmc["hbm_bytes_per_query_row"] * nq
-                traffic_note = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE), bytes per step"
+                traffic = pmc["hbm_bytes_per_query_row"] * rows_timed
+                traffic_note = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE), bytes per step of the "
+                                "timed launches")
                 break
         assert frac <= 1.0, (frac, coarse_ms, st)
         roofline = {
-            "kernel": "sknnr::coarse2_kernel<KS=%d,M=%d> (f16 split MFMA pre-filter: seeded thresholds, main hi.hi products swept on the matrix "
+            "kernel": "sknnr::coarse2_kernel<KS=%d,M=%d,WAVES=16> (f16 split MFMA pre-filter: seeded thresholds, main hi.hi products swept on the matrix "
                       "pipe with the skip test in their shadow, hits corrected (lo.hi + hi.lo) in the batched flush; lane-local top-M)" % ((d_t + 15) // 16, 6 if k <= 5 else 8),
             "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": frac, "traffic": traffic, "traffic_note": traffic_note,
             "executed_over_algorithmic_mfma": 1.0,
             "vs_f32_mfma_peak": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-            "kernel_ms_per_step": coarse_ms, "all_kernels_ms_per_step": kernel_ms,
+            "kernel_ms_per_step": coarse_ms, "kernel_rows_per_step": rows_timed, "all_kernels_ms_per_step": kernel_ms,
             "timed_calls": int(st["timed_calls"]),
             "hbm_algorithmic_GBs": alg_bytes / (kernel_ms * 1e-3) / 1e9,
             "hbm_frac_of_peak": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

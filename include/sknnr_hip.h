@@ -32,7 +32,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden; exactly these declarations are exported. */
 #pragma GCC visibility push(default)
 
-#define SKNNR_ABI_VERSION 2
+#define SKNNR_ABI_VERSION 3
 
 typedef enum sknnr_status {
     SKNNR_OK = 0,
@@ -113,6 +113,9 @@ typedef struct sknnr_stats {
     double  total_kernel_ms;   /* device time of all calls since the last reset (sums the chunks of a step) */
     double  total_coarse_ms;   /* ... of which the MFMA pre-filter kernel */
     int64_t timed_calls;       /* calls summed in the two totals */
+    int64_t coarse_rows_timed; /* query rows processed by the pre-filter launches that total_coarse_ms sums: all rows of a
+                                  call, except that when the thin last round runs beside the finaliser (side stream)
+                                  only the 16-wave bulk launch is timed -- the rows to price its time against */
 } sknnr_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

@@ -2,7 +2,7 @@
 """profiles/<round>_coarse_pmc.json from the --pmc passes of scripts/pmc_passes.sh and a
 --kernel-trace run: per-launch averages over the largest-grid launches of the pre-filter kernel.
 
-usage: scripts/pmc_coarse_json.py <pmc dir> <kernel_trace.csv> <rows of the largest launch> > out.json
+usage: scripts/pmc_coarse_json.py <pmc dir> <kernel_trace.csv> <rows of the largest launch, 0 = its thread count> > out.json
 FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads; MI355X_MICROARCH.md, HBM
 section); rocprofv3 prints FETCH_SIZE / WRITE_SIZE in KiB."""
 import collections
@@ -26,6 +26,8 @@ for r in recs:
         vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
         name = r["Kernel_Name"].split("(")[0]
 avg = {k: sum(v) / len(v) for k, v in vals.items()}
+if rows == 0:  # coarse2_kernel: one query row per thread of the launch (1024-thread workgroups sweep 1024 rows)
+    rows = grid_max
 durs = []
 for r in csv.DictReader(open(trace_csv)):
     if "coarse" in r["Kernel_Name"] and "matrix" not in r["Kernel_Name"]:

@@ -13,6 +13,6 @@ bash scripts/pmc_passes.sh "$out" --no-extras --no-cpu-baseline
 tr=$(find "$out/trace" -name "*kernel_trace.csv" | head -1)
 st=$(find "$out/trace" -name "*kernel_stats.csv" | head -1)
 python3 scripts/trim_stats.py "$st" "$out/bench_kernel_stats.csv"  # (the torch RNG kernel's name runs to kilobytes)
-python3 scripts/pmc_coarse_json.py "$out" "$tr" 10000000 > "$out/coarse_pmc.json"
+python3 scripts/pmc_coarse_json.py "$out" "$tr" 0 > "$out/coarse_pmc.json"
 cat "$out/coarse_pmc.json"
 head -8 "$out/bench_kernel_stats.csv"

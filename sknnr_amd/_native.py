@@ -31,7 +31,7 @@ ERR_UNSUPPORTED = -4
 ERR_HIP = -5
 ERR_NO_DEVICE = -6
 ERR_NONFINITE = -7
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/sknnr_hip.h declares (checked by tests/test_cabi.py)
 EXPORTED_SYMBOLS = (
@@ -84,6 +84,7 @@ class Stats(ctypes.Structure):
         ("total_kernel_ms", c_double),
         ("total_coarse_ms", c_double),
         ("timed_calls", c_int64),
+        ("coarse_rows_timed", c_int64),
     ]
 
     def as_dict(self) -> dict:

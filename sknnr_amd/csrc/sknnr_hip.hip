@@ -226,6 +226,7 @@ struct sknnr_index {
     hipStream_t st_side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     long bulk_rows_done = 0;  // rows whose pre-filter was complete at ev_fork (0: no fork in the last launch)
+    hipEvent_t ev_bulk_end = nullptr;  // the call record's end-of-pre-filter event; recorded at the fork when there is one
     bool stream_open = false;  // a sknnr_stream owns the host pipeline's slots
 
     // Device timing of calls (HIP events on the launch stream), resolved lazily by sknnr_get_stats:
@@ -234,6 +235,7 @@ struct sknnr_index {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         std::vector<std::pair<hipEvent_t, hipEvent_t>> coarse;
         size_t coarse_used = 0;
+        long coarse_rows = 0;  // rows the timed pre-filter launches of this call processed
         bool pending = false;
     };
     static constexpr int kTimingRing = 64;
@@ -800,6 +802,7 @@ static void resolve_call(sknnr_index* ix, sknnr_index::CallTiming& ct) {
     ix->stats.total_kernel_ms += ms;
     ix->stats.total_coarse_ms += cms;
     ix->stats.timed_calls += 1;
+    ix->stats.coarse_rows_timed += ct.coarse_rows;
 }
 static void resolve_timing(sknnr_index* ix) {
     // oldest first, so that last_* end up describing the newest call
@@ -990,6 +993,10 @@ int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
         int rc = launch_coarse2_waves<KS, M, kCoarse2Waves>(ix, 0, bulk_rows, kk, st);
         if (rc) return rc;
         if (tail_wg > 0 && ix->ev_fork) {  // the caller finalises these rows beside the thin round
+            if (ix->ev_bulk_end) {  // the timed region ends here: the thin round shares the device from now on
+                HIP_TRY(hipEventRecord(ix->ev_bulk_end, st));
+                ix->ev_bulk_end = nullptr;
+            }
             HIP_TRY(hipEventRecord(ix->ev_fork, st));
             ix->bulk_rows_done = bulk_rows;
         }
@@ -1251,6 +1258,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         HIP_TRY(hipEventCreate(&ct.e1));
     }
     ct.coarse_used = 0;
+    ct.coarse_rows = 0;
     HIP_TRY(hipEventRecord(ct.e0, st));
     if (check_finite && !(coarse || affine)) {
         // no prep kernel reads the rows on this path: scan them here
@@ -1283,10 +1291,13 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             HIP_TRY(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
         }
         ix->bulk_rows_done = 0;
+        ix->ev_bulk_end = ev.second;
         int rc = v2 ? launch_coarse2(ix, n_pad, coarse_list_len(kk), kk, st)
                     : launch_coarse(ix, n_pad, coarse_list_len(kk), kk, st);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(ev.second, st));
+        if (ix->ev_bulk_end) HIP_TRY(hipEventRecord(ev.second, st));  // (no fork: the whole pre-filter is timed)
+        ix->ev_bulk_end = nullptr;
+        ct.coarse_rows += ix->bulk_rows_done > 0 ? std::min<long>(ix->bulk_rows_done, n) : n;
 
         FinalizeArgs f{};
         f.s = call;  // this chunk's window of the call

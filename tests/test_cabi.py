@@ -52,7 +52,7 @@ def test_no_other_symbols_leak(native):
 
 def test_abi_version_and_last_error(native):
     lib = native.load()
-    assert lib.sknnr_abi_version() == native.ABI_VERSION == 2
+    assert lib.sknnr_abi_version() == native.ABI_VERSION == 3
     assert isinstance(lib.sknnr_last_error(), bytes)
 
 
@@ -60,7 +60,7 @@ def test_struct_layouts_match_the_header(native):
     assert ctypes.sizeof(native.QueryOpts) == 40
     assert native.QueryOpts.row_offset.offset == 32
     assert native.QueryOpts.check_finite.offset == 28
-    assert ctypes.sizeof(native.Stats) == 72
+    assert ctypes.sizeof(native.Stats) == 80
     assert native.Stats.total_kernel_ms.offset == 48
 
 
