@@ -29,6 +29,10 @@ while time.time() < t_end:
         n_ref = int(rng.choice([20000, 50000, 100003]))
         nq = int(rng.choice([5000, 20000, 50001]))
         d = int(rng.choice([8, 16, 32, 64]))
+        if rng.integers(0, 5) == 0:
+            # more than one round of pre-filter workgroups plus a thin one: the fork / join of the finaliser on the
+            # handle's side stream
+            nq, n_ref = int(rng.choice([270_000, 300_001])), 20000
     kmax = min(n_ref, 34)
     k = int(rng.integers(1, kmax + 1))
     if not big and rng.integers(0, 6) == 0:
