@@ -386,7 +386,12 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
     def _predict_chunks(self, tiles, validate, *, apply_affine, out, owner):
         weights = "uniform" if self.weights is None else self.weights
         if callable(weights):  # a Python callable runs between the search and the reduction: tile by tile
-            preds = [self._predict_engine(validate(t), apply_affine=apply_affine, owner=owner) for t in tiles]
+            # (the reorder's second key is the row's position in the WHOLE call: carry it from tile to tile)
+            preds, row = [], 0
+            for t in tiles:
+                t = validate(t)
+                preds.append(self._predict_engine(t, apply_affine=apply_affine, row_offset=row, owner=owner))
+                row += t.shape[0]
             pred = np.concatenate([p.reshape(len(p), -1) for p in preds]) if preds else np.empty((0, self.engine_.t))
             if out is not None:
                 out[:len(pred)] = pred

@@ -88,19 +88,24 @@ def assert_hamming_neighbors_match(idx, dist, ref_idx, ref_dist, fit_ids, q_ids,
     class of reference rows tied EXACTLY at the k-th distance -- numpy's argpartition picks among those
     by the internals of its introselect, which is not restated ("Hamming ties").  Every
     returned index must really be at its reported distance, and nothing strictly closer may be missing.
-    Returns the number of rows whose index sets differ (all of them boundary-tie rows)."""
+    Which tied row argpartition keeps is a property of the machine, not of the algorithm: numpy dispatches it to
+    x86-simd-sort's vectorised quick-select on AVX2 / AVX-512 hosts and to the scalar introselect elsewhere, and
+    the two keep different rows on these very fixtures (scripts/hamming_tie_dispatch.py,
+    profiles/r03_hamming_tie_dispatch.txt).
+    Returns the (sorted) row numbers whose index sets differ -- all of them boundary-tie rows; callers compare
+    everything downstream (predictions, scores) on the complement."""
     from scipy.spatial.distance import cdist
 
     idx, ref_idx = np.asarray(idx), np.asarray(ref_idx)
     dist, ref_dist = np.asarray(dist), np.asarray(ref_dist)
     np.testing.assert_allclose(np.sort(dist, axis=1), np.sort(ref_dist, axis=1), rtol=rtol, atol=atol)
     full = cdist(np.asarray(q_ids, dtype=np.float64), np.asarray(fit_ids, dtype=np.float64), "hamming", w=w)
-    differing = 0
+    differing = []
     for r in range(idx.shape[0]):
         np.testing.assert_allclose(full[r, idx[r]], dist[r], rtol=rtol, atol=atol)  # honest distances
         if sorted(idx[r].tolist()) == sorted(ref_idx[r].tolist()):
             continue
-        differing += 1
+        differing.append(r)
         kth = ref_dist[r].max()
         only_mine = set(idx[r].tolist()) - set(ref_idx[r].tolist())
         only_ref = set(ref_idx[r].tolist()) - set(idx[r].tolist())
@@ -111,4 +116,24 @@ def assert_hamming_neighbors_match(idx, dist, ref_idx, ref_dist, fit_ids, q_ids,
         if row_offset_self is not None:
             row[row_offset_self + r] = np.inf
         assert (np.sort(row)[: idx.shape[1]].max() <= kth + atol + rtol * abs(kth)), f"row {r}: a closer row is missing"
-    return differing
+        # ... and the row really is a boundary-tie row: the k-th and (k+1)-th smallest distances are equal
+        srt = np.sort(row)
+        assert srt[idx.shape[1] - 1] == pytest.approx(srt[idx.shape[1]], rel=rtol, abs=atol), f"row {r}: sets differ without a tie"
+    return np.asarray(differing, dtype=np.int64)
+
+
+def rows_without(n_rows, tie_rows):
+    """Boolean mask of the rows that are NOT in ``tie_rows``."""
+    keep = np.ones(n_rows, dtype=bool)
+    keep[np.asarray(tie_rows, dtype=np.int64)] = False
+    return keep
+
+
+def mixed_forest_y_fit(y_train):
+    """The ``y_fit`` of the reference's mixed regression / classification forest test
+    (/root/reference/tests/test_regressions.py:157-176): Total_BA (numeric -> regression forest) and the
+    species of maximum basal area reclassed to ABGR_BA / TSHE_BA / OTHER (strings -> classification forest)."""
+    cols = [c for c in y_train.columns if c.endswith("_BA") and c != "Total_BA"]
+    max_species = y_train[cols].idxmax(axis=1)
+    max_species = max_species.where(max_species.isin(["ABGR_BA", "TSHE_BA"]), other="OTHER")
+    return y_train[["Total_BA"]].assign(MAX_SPECIES=max_species)
