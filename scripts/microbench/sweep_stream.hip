@@ -1,0 +1,202 @@
+// Microbenchmark (development aid, round 3): the sweep of the pre-filter WITHOUT visits, as an instruction stream.
+//   shipped   : coarse2_kernel's tile step (both units' MFMAs back to back, first tree in the shadow of the second
+//               unit's MFMAs, second tree and the tile's LDS wait exposed; |r'|^2 loaded into the accumulator in place)
+//   pipelined : coarse3's unit_step (MFMAs of unit u+1 first, tree of unit u in their shadow, across tiles and stages;
+//               |r'|^2 and hi fragments in register sets of their own, loaded one tile ahead)
+// at 16 / 12 / 8 waves per CU and 2 / 3 / 4 q-blocks per wave, on random f16 operands (the chip is power-limited on
+// real data: profiles/r02_mfma_power.txt), with the real LDS staging (LDS-DMA, double buffered, 16 tiles per stage).
+// Reported per variant: ms, SIMD-cycles per unit (32 refs x 32 queries) at the measured clock, TFLOP/s.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/microbench/sweep_stream.hip -o scripts/microbench/sweep_stream
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../sknnr_amd/csrc/coarse3.hip.h"
+
+using namespace sknnr;
+
+template <int KS, int WAVES, int NQB, int MODE>
+__global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
+sweep_kernel(const char* __restrict__ rhi, int n_stages, const uint4* __restrict__ qimg, float thr, float* out,
+             unsigned long long* clk) {
+    constexpr int TPS = 16;
+    constexpr int TB = tile2_bytes(KS);
+    constexpr int STAGE = TPS * TB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    half8 bh[NQB][KS];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            bh[qb][s] = __builtin_bit_cast(half8, qimg[(size_t)(((blockIdx.x * WAVES + wave) * NQB + qb) % 4096) * KS * 64 + s * 64 + lane]);
+    float loose[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) loose[qb] = thr;
+    int visits = 0;
+
+    auto load_c = [&](const char* tb, floatx16& acc) {
+        const floatx4* cp = (const floatx4*)(tb + KS * 1024 + half * 64);
+        const floatx4 c_0 = cp[0], c_1 = cp[1], c_2 = cp[2], c_3 = cp[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i] = c_0[i]; acc[4 + i] = c_1[i]; acc[8 + i] = c_2[i]; acc[12 + i] = c_3[i]; }
+    };
+    auto load_hi = [&](const char* tb, half8 (&ah)[KS]) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ah[s] = *(const half8*)(tb + s * 1024 + lane * 16);
+    };
+    auto test = [&](float m, int qb) {
+        if (__builtin_amdgcn_ballot_w64(m < loose[qb]) != 0) { visits += 1; loose[qb] -= 1.0f; }
+    };
+
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    stage_copy(rhi, smem, STAGE, wave, lane, WAVES);
+    __syncthreads();
+    if constexpr (MODE == 0) {
+        static_assert(MODE != 0 || NQB == 2, "the shipped tile step handles two q-blocks");
+        for (int st = 0; st < n_stages; ++st) {
+            const char* cur = smem + (st & 1) * STAGE;
+            if (st + 1 < n_stages) stage_copy(rhi + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
+            float g[5], m1;
+#pragma unroll 1
+            for (int t = 0; t < TPS; ++t) {
+                const char* tb = cur + t * TB;
+                floatx16 acc0, acc1;
+                half8 ah[KS];
+                load_hi(tb, ah);
+                load_c(tb, acc1);
+                tile_issue_and_test<KS>(acc0, acc1, ah, bh[0], bh[1], g, m1);
+                test(m1, 0);
+                step_test_only(acc1, g, m1);
+                test(m1, 1);
+            }
+            __syncthreads();
+        }
+    } else {
+        // pipelined: acc[u & 1] computes unit u while unit u - 1 is tested; operands of tile t + 1 are loaded during tile t
+        floatx16 accA, accB, cb[2];
+        half8 ah[2][KS];
+        float g[5], m1;
+        // nothing is pending at the start: the first step tests a set of FLT_MAX values (never below a threshold)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accB[i] = FLT_MAX;
+        for (int st = 0; st < n_stages; ++st) {
+            const char* cur = smem + (st & 1) * STAGE;
+            if (st + 1 < n_stages) stage_copy(rhi + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
+            load_hi(cur, ah[0]);
+            load_c(cur, cb[0]);
+#pragma unroll 1
+            for (int t2 = 0; t2 < TPS; t2 += 2) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {  // two tiles per trip: register-set roles are compile-time constants
+                    const int t = t2 + tt;
+                    // the NQB units of this tile, alternating between the two accumulator sets (unit number parity); the
+                    // operands of tile t + 1 are requested right behind the tile's first MFMA (the stage's last tile has
+                    // nothing to request)
+                    auto prefetch = [&]() {
+                        if (tt == 0 || t + 1 < TPS) {
+                            load_hi(cur + (t + 1) * TB, ah[tt ^ 1]);
+                            load_c(cur + (t + 1) * TB, cb[tt ^ 1]);
+                        }
+                    };
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb) {
+                        if (qb == 0) {
+                            if ((tt * NQB & 1) == 0) unit_step<KS>(accA, accB, cb[tt], ah[tt], bh[qb], g, m1, prefetch);
+                            else unit_step<KS>(accB, accA, cb[tt], ah[tt], bh[qb], g, m1, prefetch);
+                        } else {
+                            if (((tt * NQB + qb) & 1) == 0) unit_step<KS>(accA, accB, cb[tt], ah[tt], bh[qb], g, m1);
+                            else unit_step<KS>(accB, accA, cb[tt], ah[tt], bh[qb], g, m1);
+                        }
+                        test(m1, qb == 0 ? NQB - 1 : qb - 1);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // drain: the last unit (its number is odd: 16 tiles per stage) waits in accB
+        step_test_only(accB, g, m1);
+        test(m1, NQB - 1);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+    if (visits != 0 || thr > 1e30f) out[blockIdx.x * WAVES * 64 + threadIdx.x] = (float)visits + loose[0];
+}
+
+static char* g_img;
+static uint4* g_q;
+static float* g_out;
+static unsigned long long* g_clk;
+
+template <int KS, int WAVES, int NQB, int MODE>
+void run(const char* name, int n_stages, int rounds) {
+    constexpr int TPS = 16;
+    const size_t sh = 2 * (size_t)TPS * tile2_bytes(KS);
+    auto kern = sweep_kernel<KS, WAVES, NQB, MODE>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    const int wgs = 256 * rounds;
+    kern<<<wgs, WAVES * 64, sh>>>(g_img, n_stages, g_q, -1e30f, g_out, g_clk);
+    (void)hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    unsigned long long c[2] = {0, 0};
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        kern<<<wgs, WAVES * 64, sh>>>(g_img, n_stages, g_q, -1e30f, g_out, g_clk);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) { best = ms; (void)hipMemcpy(c, g_clk, 16, hipMemcpyDeviceToHost); }
+    }
+    hipError_t err = hipGetLastError();
+    const double units = (double)wgs * WAVES * NQB * n_stages * TPS;
+    const double ghz = (double)c[0] / ((double)c[1] * 10.0);
+    const double simd_cycles_per_unit = best * 1e-3 * ghz * 1e9 * 1024.0 / units;  // 1024 SIMDs
+    const double tf = units * 2.0 * 32 * 32 * 16 * KS / (best * 1e-3) / 1e12;
+    printf("%-34s KS=%d %2d waves x %d q-blocks: %8.3f ms  %6.1f SIMD-cycles/unit @ %.2f GHz  %7.1f TFLOP/s (%.3f of 2.5 PF) %s\n", name, KS,
+           WAVES, NQB, best, simd_cycles_per_unit, ghz, tf, tf / 2500.0, err == hipSuccess ? "" : hipGetErrorString(err));
+}
+
+int main() {
+    const int n_stages = 98;  // 1568 tiles = 50,176 reference rows
+    std::vector<unsigned short> img((size_t)n_stages * 16 * tile2_bytes(4) / 2);
+    srand(1);
+    for (auto& v : img) {  // random f16 in [-128, 128): sign, exponent 15..21, random mantissa
+        const unsigned e = 15 + rand() % 7;
+        v = (unsigned short)(((rand() & 1) << 15) | (e << 10) | (rand() & 1023));
+    }
+    (void)hipMalloc(&g_img, img.size() * 2);
+    (void)hipMemcpy(g_img, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+    std::vector<unsigned short> q((size_t)4096 * 4 * 64 * 8);
+    for (auto& v : q) {
+        const unsigned e = 15 + rand() % 7;
+        v = (unsigned short)(((rand() & 1) << 15) | (e << 10) | (rand() & 1023));
+    }
+    (void)hipMalloc(&g_q, q.size() * 2);
+    (void)hipMemcpy(g_q, q.data(), q.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMalloc(&g_out, 256 * 64 * 1024 * 4);
+    (void)hipMalloc(&g_clk, 64);
+    // (the |r'|^2 slots of the records hold random f16 pairs read as f32: any finite or non-finite value, irrelevant here
+    //  -- thresholds are -1e30 and NaN compares false)
+    for (int pass = 0; pass < 2; ++pass) {  // second pass: the chip is warm
+        run<2, 16, 2, 0>("shipped tile step", n_stages, 8);
+        run<2, 16, 2, 1>("pipelined", n_stages, 8);
+        run<2, 12, 2, 1>("pipelined", n_stages, 8);
+        run<2, 8, 2, 1>("pipelined", n_stages, 8);
+        run<2, 12, 3, 1>("pipelined", n_stages, 8);
+        run<2, 8, 3, 1>("pipelined", n_stages, 8);
+        run<2, 8, 4, 1>("pipelined", n_stages, 8);
+        run<2, 4, 4, 1>("pipelined", n_stages, 8);
+        run<1, 16, 2, 0>("shipped tile step", n_stages, 8);
+        run<1, 12, 2, 1>("pipelined", n_stages, 8);
+        run<1, 12, 3, 1>("pipelined", n_stages, 8);
+        run<4, 16, 2, 0>("shipped tile step", n_stages, 4);
+        run<4, 12, 2, 1>("pipelined", n_stages, 4);
+        run<4, 8, 3, 1>("pipelined", n_stages, 4);
+    }
+    return 0;
+}

@@ -147,6 +147,21 @@ __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], fl
 // coarse_counters[]; read back by sknnr_get_stats and printed to stderr.  Off in the product build.
 #ifdef SKNNR_COARSE_TIMERS
 __device__ unsigned long long coarse_timers[8];
+#define TICK()                                  \
+    do {                                        \
+        asm volatile("" ::: "memory");          \
+        tk = __builtin_readcyclecounter();      \
+        asm volatile("" ::: "memory");          \
+    } while (0)
+#define TSTAMP(i)            \
+    do {                     \
+        tk0 = tk;            \
+        TICK();              \
+        tm[i] += tk - tk0;   \
+    } while (0)
+#else
+#define TICK() ((void)0)
+#define TSTAMP(i) ((void)0)
 #endif
 #ifdef SKNNR_COARSE_COUNTERS
 __device__ unsigned long long coarse_counters[16];
@@ -357,23 +372,8 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
 #ifdef SKNNR_COARSE_TIMERS  // development aid: where one wave's cycles go (s_memtime stamps)
     unsigned long long tm[8] = {};
     unsigned long long tk = 0, tk0 = 0;
-#define TICK()                                  \
-    do {                                        \
-        asm volatile("" ::: "memory");          \
-        tk = __builtin_readcyclecounter();      \
-        asm volatile("" ::: "memory");          \
-    } while (0)
-#define TSTAMP(i)            \
-    do {                     \
-        tk0 = tk;            \
-        TICK();              \
-        tm[i] += tk - tk0;   \
-    } while (0)
     TICK();
     const unsigned long long t_begin = tk;
-#else
-#define TICK() ((void)0)
-#define TSTAMP(i) ((void)0)
 #endif
     stage_copy(rimg, smem, STAGE, wave, lane, WAVES);
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0

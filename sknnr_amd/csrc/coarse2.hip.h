@@ -49,12 +49,16 @@ __host__ __device__ constexpr int tile2_bytes(int ks) { return ks * 1024 + 128; 
 // 16-wave workgroups: one per CU, 16 tiles per stage; 8-wave workgroups: two per CU (each with its own stages of
 // 8 tiles), so that a workgroup waiting at its stage barrier for a flushing wave leaves the SIMDs to the other one
 __host__ __device__ constexpr int tiles_per_stage2(int ks) { return ks <= 2 ? SKNNR_V2_TPS : SKNNR_V2_TPS / 2; }
-constexpr int kSeedTiles = 64;
+#ifndef SKNNR_SEED_TILES
+#define SKNNR_SEED_TILES 64
+#endif
+constexpr int kSeedTiles = SKNNR_SEED_TILES;
 constexpr int kCoarse2Waves = SKNNR_V2_WAVES;
 constexpr int kCoarse2Nqb = 2;
 constexpr int kQueueCap = 5;      // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
 constexpr int kQueueFlushAt = 3;  // a visit ends with a flush once some lane holds this many
-__host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb * kQueueCap * 64 * 8; }
+// per wave: the queues [q-block][entry][lane] 8-byte pairs, then the row behind every lane's column [q-block][lane] (4 bytes)
+__host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb * kQueueCap * 64 * 8 + kCoarse2Nqb * 64 * 4; }
 // measured against coarse_kernel on 4.19M x 50k rows (profiles/r02_v2_vs_v1.txt): 6-entry lists win for KS <= 4, 8-entry
 // lists for KS <= 3 (KS = 4 with 8-entry lists spills 88 bytes and loses)
 __host__ __device__ constexpr bool coarse2_supported(int ks, int m) { return (m == 6 && ks <= 4) || (m == 8 && ks <= 3); }
@@ -143,16 +147,21 @@ __device__ __forceinline__ void tile_issue_and_test(floatx16& a, floatx16& c, co
 // last, thinly filled round of workgroups and for small calls: spread over four times as many CUs with one wave per
 // SIMD, where a wave no longer shares its matrix pipe (host side: launch_coarse2_ks).
 template <int KS, int M, int WAVES = kCoarse2Waves>
-__global__ void __launch_bounds__(WAVES * 64, 4)
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 4)
 coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: KS KiB][|r'|^2: 128 B]
                const char* __restrict__ rlo,    // n_stages * TPS records [lo: KS KiB]
                int n_stages,
-               const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments
+               const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments (rows of the chunk)
                const double* __restrict__ qnc,  // [n_qblocks*32] |q'|^2 (0 for padding rows)
                float skip_scale,                // 2^-9 * max|r'| * (1 + slack): margin = skip_scale * |q'|
                int n_sentinel,                  // M - (neighbours searched + 1)
                float* __restrict__ cand_val,    // [n_qblocks*32][2][M]
-               int* __restrict__ cand_idx) {
+               int* __restrict__ cand_idx,
+               // Query bucketing (bucket.hip.h): the kernel works on POSITIONS pos0 .. of the chunk; position p holds row
+               // qperm[p] (null: the row itself).  A workgroup starts its sweep at the stage its middle row's cell names.
+               int pos0, const int* __restrict__ qperm, const unsigned char* __restrict__ qcell,
+               const int* __restrict__ cell_stage,
+               uint4* __restrict__ qlo) {       // bucketed calls: [n_qblocks][KS][64] lo fragments in POSITION order (scratch)
     constexpr int TPS = tiles_per_stage2(KS);
     constexpr int TB = tile2_bytes(KS);
     constexpr int STAGE = TPS * TB;
@@ -164,21 +173,68 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
     const int half = lane >> 5;
     const int qb0 = (blockIdx.x * WAVES + wave) * NQB;
     const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue2_bytes_per_wave() + lane * 8);
+    // the row behind this lane's column of q-block qb: needed at the start, by every flush and at the end -- kept in LDS
+    // (two registers more would spill), and the rotation of the sweep (workgroup-uniform)
+    const unsigned qrow_lds = lds_addr_of(smem + 2 * STAGE + wave * queue2_bytes_per_wave() + NQB * kQueueCap * 512 + lane * 4);
+    auto qrow_of = [&](int qb) {
+        int r;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(qrow_lds + qb * 256) : "memory");
+        return r;
+    };
+    int st0 = 0;
+    if (qperm) {
+        const int mid = qperm[pos0 + (blockIdx.x * WAVES + WAVES / 2) * NQB * 32];
+        st0 = __builtin_amdgcn_readfirstlane(cell_stage[qcell[mid]]);
+    }
+    // 16-B fragment (part: 0 hi / 1 lo, K-step s) of this lane's column: row r sits in q-block r / 32, column r % 32
+    auto qfrag = [&](int r, int part, int s) {
+        return __builtin_bit_cast(half8, qimg[((size_t)((r >> 5) * 2 + part) * KS + s) * 64 + (lane & 32) + (r & 31)]);
+    };
+    auto stage_of = [&](int st) {  // the st-th stage of this workgroup's sweep
+        const int i = st0 + st;
+        return i >= n_stages ? i - n_stages : i;
+    };
 
     // Queries of this wave: hi fragments resident for the whole sweep; the lo fragments are only needed by
     // the flush, which fetches them again (16 VGPRs that the second accumulator set needs more).
     half8 bh[NQB][KS];
+    float qnorm[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
+        const int pos = pos0 + (qb0 + qb) * 32 + (lane & 31);
+        const int r = qperm ? qperm[pos] : pos;
+        asm volatile("ds_write_b32 %0, %1" ::"v"(qrow_lds + qb * 256), "v"(r) : "memory");
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-            bh[qb][s] = __builtin_bit_cast(half8, qimg[((size_t)((qb0 + qb) * 2 + 0) * KS + s) * 64 + lane]);
+        for (int s = 0; s < KS; ++s) bh[qb][s] = qfrag(r, 0, s);
+        qnorm[qb] = (float)sqrt(qnc[r]);
+        // The flush needs the lo fragments of this lane's column again and again: a bucketed call copies them once into
+        // position order (this wave's own 1-KiB blocks, written and later read by the same lanes), so that every later
+        // fetch is one coalesced 1-KiB load instead of 64 scattered 16-byte ones.
+        if (qperm) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                qlo[((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane] = __builtin_bit_cast(uint4, qfrag(r, 1, s));
+        }
     }
 
+#ifdef SKNNR_V2_BL_RESIDENT  // experiment: the queries' lo fragments stay in registers (12-wave geometry: 168 VGPRs)
+    half8 blr[NQB][KS];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            blr[qb][s] = qfrag(qrow_of(qb), 1, s);
+#endif
     float vals[NQB][M];
     int idxs[NQB][M];
 #ifdef SKNNR_COARSE_COUNTERS
     unsigned ctr[16] = {};
+#endif
+#ifdef SKNNR_COARSE_TIMERS  // development aid: where one wave's cycles go (s_memtime stamps; the stamps cost time themselves)
+    unsigned long long tm[8] = {};
+    unsigned long long tk = 0, tk0 = 0;
+    TICK();
+    const unsigned long long t_begin = tk;
 #endif
     float loose[NQB], margin[NQB];  // loose = threshold + margin: what a MAIN product is tested against
     int cnt[NQB];                   // (a lane that had to drop hits sets its loose to NaN: nothing is below NaN, the
@@ -193,7 +249,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         cnt[qb] = 0;
-        margin[qb] = skip_scale * (float)sqrt(qnc[(size_t)(qb0 + qb) * 32 + (lane & 31)]) + 1e-30f;
+        margin[qb] = skip_scale * qnorm[qb] + 1e-30f;
         loose[qb] = FLT_MAX;
         reset_lists(qb);
     }
@@ -223,12 +279,20 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 
     // ---- flush: correct every queued entry, insert, tighten the pair's threshold ---------------------------
     auto flush = [&](int qb) {
+        TSTAMP(1);  // (visit scan up to here)
         const unsigned qlane = qwave + qb * (kQueueCap * 512);
         const int frag_off = (32 * half) * 16;  // this lane's K half inside a fragment row group
         half8 bl[KS];  // this lane's lo fragments of the queries (not kept during the sweep)
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-            bl[s] = __builtin_bit_cast(half8, qimg[((size_t)((qb0 + qb) * 2 + 1) * KS + s) * 64 + lane]);
+        for (int s = 0; s < KS; ++s) {
+#ifdef SKNNR_V2_BL_RESIDENT
+            bl[s] = blr[qb][s];
+#else
+            const uint4* src = qperm ? qlo + ((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane
+                                     : qimg + ((size_t)((pos0 / 32 + qb0 + qb) * 2 + 1) * KS + s) * 64 + lane;
+            bl[s] = __builtin_bit_cast(half8, *src);
+#endif
+        }
         CTR(6, 1);
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt[qb]) != 0; ++i) {
             CTR(7, 1);
@@ -257,6 +321,31 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
             };
 #ifdef SKNNR_V2_NO_CORR  // timing experiment: entries inserted with their main values
             const float part_own = 0.f, part_par = (float)pos_par * 0.f;
+#elif defined(SKNNR_V2_FLUSH_COMBINED)  // experiment: the gathers of both entries go out together (one round trip per iteration)
+            half8 fo[2 * KS], fp[2 * KS];
+            auto gather = [&](int pos, half8 (&f)[2 * KS]) {
+                const unsigned row = (unsigned)(pos & 31) * 16u + (unsigned)frag_off;
+                const unsigned oh = (unsigned)(pos >> 5) * (unsigned)TB + row;
+                const unsigned ol = (unsigned)(pos >> 5) * (unsigned)(KS * 1024) + row;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    f[2 * s] = *(const half8*)(rlo + ol + s * 1024);
+                    f[2 * s + 1] = *(const half8*)(rhi + oh + s * 1024);
+                }
+            };
+            auto reduce = [&](const half8 (&f)[2 * KS]) {
+                float acc = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    acc = dot8(f[2 * s], bh[qb][s], acc);
+                    acc = dot8(f[2 * s + 1], bl[s], acc);
+                }
+                return acc;
+            };
+            gather(pos_own, fo);
+            gather(pos_par, fp);
+            const float part_own = reduce(fo);
+            const float part_par = reduce(fp);
 #else
             const float part_own = partial(pos_own);
             __builtin_amdgcn_sched_barrier(0);
@@ -269,6 +358,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         cnt[qb] = 0;
         const float tight = pair_union_rank_m<M>(vals[qb]) + margin[qb];
         loose[qb] = loose[qb] != loose[qb] ? loose[qb] : min2f(loose[qb], tight);  // (NaN = poisoned: stays)
+        TSTAMP(2);  // flush
     };
 
     // ---- one unit: skip test on the main products, visit = queue every value below threshold + margin ------
@@ -282,6 +372,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         CTR(0, 1);
         if (__builtin_amdgcn_ballot_w64(m1 < loose[qb]) == 0) return;
         CTR(1, 1);
+        TSTAMP(0);  // sweep (everything since the last stamp that is not a visit / flush / barrier)
 #ifdef SKNNR_V2_SWEEP_ONLY  // timing experiment: no visits (the margin keeps the sweep alive for the compiler)
         margin[qb] += 1e-30f;
         return;
@@ -310,6 +401,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         }
         if (want > kQueueCap) loose[qb] = __builtin_nanf("");
         if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) flush(qb);
+        else TSTAMP(1);  // visit scan without a flush
     };
 
     // ---- seeding: a valid starting threshold from the first kSeedTiles tiles ------------------------------
@@ -320,12 +412,12 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
     if (n_tiles >= 2 * kSeedTiles) {
 #endif
         constexpr int SEED_STAGES = kSeedTiles / TPS;
-        stage_copy(rhi, smem, STAGE, wave, lane, WAVES);
+        stage_copy(rhi + (size_t)stage_of(0) * STAGE, smem, STAGE, wave, lane, WAVES);
         __syncthreads();
         for (int st = 0; st < SEED_STAGES; ++st) {
             const char* cur = smem + (st & 1) * STAGE;
             if (st + 1 < SEED_STAGES)
-                stage_copy(rhi + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
+                stage_copy(rhi + (size_t)stage_of(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
 #pragma unroll 1
             for (int t = 0; t < TPS; ++t) {
                 const char* tb = cur + t * TB;
@@ -356,20 +448,22 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
             loose[qb] = seed < FLT_MAX ? seed + 2.0f * margin[qb] : FLT_MAX;
             reset_lists(qb);
         }
+        TSTAMP(4);  // seeding pass
     }
 
     // ---- the sweep ---------------------------------------------------------------------------------------------
-    stage_copy(rhi, smem, STAGE, wave, lane, WAVES);
+    stage_copy(rhi + (size_t)stage_of(0) * STAGE, smem, STAGE, wave, lane, WAVES);
     __syncthreads();
     for (int st = 0; st < n_stages; ++st) {
         const char* cur = smem + (st & 1) * STAGE;
         if (st + 1 < n_stages)
-            stage_copy(rhi + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
+            stage_copy(rhi + (size_t)stage_of(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
+        const int tile0 = stage_of(st) * TPS;
         float g[5], m1;
 #pragma unroll SKNNR_V2_UNROLL
         for (int t = 0; t < TPS; ++t) {
             const char* tb = cur + t * TB;
-            const int tile_no = st * TPS + t;
+            const int tile_no = tile0 + t;
             floatx16 acc0, acc1;
             half8 ah[KS];
             load_hi(tb, ah);
@@ -379,17 +473,24 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
             step_test_only(acc1, g, m1);
             process(acc1, g, m1, tile_no, 1);
         }
+        TSTAMP(0);
+#ifdef SKNNR_V2_NO_BARRIER  // timing experiment only (results are wrong: a wave may read a stage that is being replaced)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with `cur`
+#endif
+        TSTAMP(3);  // stage barrier
     }
 
 #ifdef SKNNR_COARSE_COUNTERS
     if (lane == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(&coarse_counters[i], (unsigned long long)ctr[i]);
 #endif
+    TSTAMP(0);
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         flush(qb);
-        const size_t q = (size_t)(qb0 + qb) * 32 + (lane & 31);
+        const size_t q = (size_t)qrow_of(qb);
         const size_t base = (q * 2 + half) * M;
         // a poisoned query (dropped hits) must fail the certificate: a NaN bound never certifies
         const int mine = loose[qb] != loose[qb] ? 1 : 0;
@@ -400,6 +501,12 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
             cand_idx[base + i] = idxs[qb][i];
         }
     }
+#ifdef SKNNR_COARSE_TIMERS
+    TICK();
+    tm[7] = tk - t_begin;
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&coarse_timers[i], tm[i]);
+#endif
 }
 
 }  // namespace sknnr

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "bucket.hip.h"
 #include "coarse.hip.h"
 
 namespace sknnr {
@@ -44,6 +45,8 @@ struct PrepArgs {
     double* qnc;           // (nq) out; +inf marks a row whose image overflows f16 (never certified)
     int* status;           // device word, or null: bit 0 = a query value is NaN, bit 1 = infinite
                            // (SKL/utils/validation.py _assert_all_finite, reached from SKL/neighbors/_base.py:838-845)
+    CellTreeDev tree;      // query bucketing (bucket.hip.h): the register-resident kernel also names every row's cell
+    unsigned char* cell;   // (nq) out, or null
 };
 
 // |b| at or above this has no finite f16 image (65504 is the largest f16; the margin keeps hi + lo exact)
@@ -204,6 +207,22 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
         }
     }
     report_nonfinite(a.status, has_nan, has_inf);
+    if (a.cell && live) {
+        // cell of the row in the tree over the reference rows' principal axes: float32, on the transformed values at hand
+        float z[kCellMaxDepth];
+#pragma unroll
+        for (int l = 0; l < kCellMaxDepth; ++l) z[l] = 0.f;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            if (k < a.d) {
+                const float v = (float)acc[k] - a.tree.centre[k];
+#pragma unroll
+                for (int l = 0; l < kCellMaxDepth; ++l)
+                    if (l < a.tree.depth) z[l] = fmaf(v, a.tree.axes[l * a.d + k], z[l]);
+            }
+        }
+        a.cell[q] = (unsigned char)cell_of(z, a.tree);
+    }
     if (a.xt) {
         // Transformed rows go out through a wave-private LDS tile (64 rows x 8 KS columns, two
         // passes) so that every store instruction writes whole 64..128-byte row segments instead of
@@ -370,6 +389,10 @@ struct FinalizeArgs {
     int* fail_list;         // call-relative row ids of uncertified queries
     int fail_base;          // call-relative id of this launch's row 0
     int* fail_count;
+    // Bucketed calls (bucket.hip.h): the launch covers positions pos0 .. pos0 + s.nq - 1 of the chunk and position p
+    // holds row qperm[p] of the chunk; every per-row array is then indexed by that row.  Null: position = row.
+    const int* qperm;
+    long pos0;
 };
 
 // Lane exchange inside the group of LPQ lanes that share a query.  A group is LPQ/16 DPP rows:
@@ -518,6 +541,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const int c = (int)(gt % LPQ);
     const bool live = q < s.nq;
     if (!live) q = s.nq - 1;  // keep the lane for the exchanges; it writes nothing
+    if (a.qperm) q = a.qperm[a.pos0 + q];
 
     const int list = c / M, slot = c % M;
     const bool has_slot = slot < a.m_list;

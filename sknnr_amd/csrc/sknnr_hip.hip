@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 
+#include "bucket.hip.h"
 #include "coarse.hip.h"
 #include "coarse2.hip.h"
 #include "exact.hip.h"
@@ -193,6 +194,14 @@ struct sknnr_index {
     DevBuf<char> rhi2, rlo2;  // coarse2_kernel's image: [hi | |r'|^2] records for the LDS stages, lo fragments apart
     int n_stages2 = 0;
     DevBuf<int> perm;  // image position -> reference row (rows are imaged by increasing centred norm)
+    // Second-generation image in CELL order (bucket.hip.h): a median-split tree over the leading principal axes
+    DevBuf<int> perm2;             // its image position -> reference row
+    int cell_depth = 0;            // 0: the second image is in the first one's order, no bucketing
+    DevBuf<float> cell_axes, cell_centre, cell_thr;
+    DevBuf<int> cell_stage;        // [2^depth] stage at which a workgroup of that cell starts its sweep
+    DevBuf<unsigned char> qcell;   // workspace: cell of every query row of the chunk
+    DevBuf<int> qperm, cell_hist;  // workspace: position -> row; [2][kCellMax] rows per cell / cursors
+    DevBuf<uint4> qlo;             // workspace: the queries' lo fragments in position order (written by the pre-filter itself)
 
     // workspace (one chunk)
     DevBuf<double> xt, qnc, xstage, dist_stage, pred_stage;
@@ -250,6 +259,9 @@ struct sknnr_index {
             b->release();
         rimg.release();
         perm.release();
+        perm2.release();
+        cell_axes.release(); cell_centre.release(); cell_thr.release(); cell_stage.release();
+        qcell.release(); qperm.release(); cell_hist.release(); qlo.release();
         qimg.release();
         cand_val.release();
         cand_idx.release();
@@ -447,6 +459,125 @@ static int choose_image_order(const double* ref, int64_t n_ref, int d, const std
     return choice;
 }
 
+
+// ----------------------------------------------------------------------------------------
+// cell order of the second-generation image (bucket.hip.h)
+// ----------------------------------------------------------------------------------------
+namespace {
+
+// Eigenvectors of a symmetric d x d matrix (cyclic Jacobi), sorted by decreasing eigenvalue: vec[i * d + k] = k-th
+// component of the i-th vector.
+void symmetric_eigen(std::vector<double> a, int d, std::vector<double>& val, std::vector<double>& vec) {
+    std::vector<double> v((size_t)d * d, 0.0);
+    for (int i = 0; i < d; ++i) v[(size_t)i * d + i] = 1.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < d; ++p)
+            for (int q = p + 1; q < d; ++q) off += a[(size_t)p * d + q] * a[(size_t)p * d + q];
+        if (off < 1e-22) break;
+        for (int p = 0; p < d; ++p)
+            for (int q = p + 1; q < d; ++q) {
+                const double apq = a[(size_t)p * d + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (a[(size_t)q * d + q] - a[(size_t)p * d + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < d; ++k) {  // columns p, q
+                    const double akp = a[(size_t)k * d + p], akq = a[(size_t)k * d + q];
+                    a[(size_t)k * d + p] = c * akp - sn * akq;
+                    a[(size_t)k * d + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < d; ++k) {  // rows p, q
+                    const double apk = a[(size_t)p * d + k], aqk = a[(size_t)q * d + k];
+                    a[(size_t)p * d + k] = c * apk - sn * aqk;
+                    a[(size_t)q * d + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < d; ++k) {  // accumulate the rotation (columns of v are the vectors)
+                    const double vkp = v[(size_t)k * d + p], vkq = v[(size_t)k * d + q];
+                    v[(size_t)k * d + p] = c * vkp - sn * vkq;
+                    v[(size_t)k * d + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    std::vector<int> order(d);
+    for (int i = 0; i < d; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return a[(size_t)x * d + x] > a[(size_t)y * d + y]; });
+    val.resize(d);
+    vec.assign((size_t)d * d, 0.0);
+    for (int i = 0; i < d; ++i) {
+        val[i] = a[(size_t)order[i] * d + order[i]];
+        for (int k = 0; k < d; ++k) vec[(size_t)i * d + k] = v[(size_t)k * d + order[i]];
+    }
+}
+
+struct CellTree {
+    int depth = 0;
+    std::vector<float> axes, centre, thr;  // [depth][d], [d], [2^depth - 1]
+    std::vector<int> code;                 // cell of every reference row
+};
+
+// Median-split tree over the `depth` leading principal axes of the centred reference rows: level l splits every
+// node at the median of its rows' coordinate along axis l.  The reference rows are compared with the same float32
+// arithmetic as the device uses for the queries (cell_hist_kernel), so a query that IS a reference row lands in
+// that row's cell.
+CellTree build_cell_tree(const double* ref, int64_t n_ref, int d, const std::vector<double>& mu, int depth) {
+    CellTree t;
+    t.depth = depth;
+    const int64_t n_cov = std::min<int64_t>(n_ref, 65536), stride = n_ref / n_cov;
+    std::vector<double> cov((size_t)d * d, 0.0), v((size_t)d);
+    for (int64_t i = 0; i < n_cov; ++i) {
+        const double* r = ref + i * stride * d;
+        for (int a = 0; a < d; ++a) v[(size_t)a] = r[a] - mu[(size_t)a];
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b <= a; ++b) cov[(size_t)a * d + b] += v[(size_t)a] * v[(size_t)b];
+    }
+    for (int a = 0; a < d; ++a)
+        for (int b = 0; b <= a; ++b) cov[(size_t)b * d + a] = cov[(size_t)a * d + b] = cov[(size_t)a * d + b] / (double)n_cov;
+    std::vector<double> val, vec;
+    symmetric_eigen(cov, d, val, vec);
+    t.axes.resize((size_t)depth * d);
+    t.centre.resize((size_t)d);
+    for (int l = 0; l < depth; ++l)
+        for (int k = 0; k < d; ++k) t.axes[(size_t)l * d + k] = (float)vec[(size_t)l * d + k];
+    for (int k = 0; k < d; ++k) t.centre[(size_t)k] = (float)mu[(size_t)k];
+    // coordinates of every row along the axes (the device's arithmetic: float32 fma chain over k)
+    std::vector<float> z((size_t)n_ref * depth);
+    for (int64_t i = 0; i < n_ref; ++i) {
+        float acc[kCellMaxDepth] = {};
+        for (int k = 0; k < d; ++k) {
+            const float x = (float)ref[i * d + k] - t.centre[(size_t)k];
+            for (int l = 0; l < depth; ++l) acc[l] = std::fmaf(x, t.axes[(size_t)l * d + k], acc[l]);
+        }
+        for (int l = 0; l < depth; ++l) z[(size_t)i * depth + l] = acc[l];
+    }
+    t.thr.assign(((size_t)1 << depth) - 1, 0.f);
+    t.code.assign((size_t)n_ref, 0);
+    std::vector<std::vector<int>> nodes(1);
+    nodes[0].resize((size_t)n_ref);
+    for (int64_t i = 0; i < n_ref; ++i) nodes[0][(size_t)i] = (int)i;
+    for (int l = 0; l < depth; ++l) {
+        std::vector<std::vector<int>> next(nodes.size() * 2);
+        for (size_t n = 0; n < nodes.size(); ++n) {
+            std::vector<int>& rows = nodes[n];
+            float split = 0.f;
+            if (!rows.empty()) {
+                std::vector<float> zz(rows.size());
+                for (size_t j = 0; j < rows.size(); ++j) zz[j] = z[(size_t)rows[j] * depth + l];
+                std::nth_element(zz.begin(), zz.begin() + zz.size() / 2, zz.end());
+                split = zz[zz.size() / 2];
+            }
+            t.thr[((size_t)1 << l) - 1 + n] = split;
+            for (int r : rows) next[2 * n + (z[(size_t)r * depth + l] >= split ? 1 : 0)].push_back(r);
+        }
+        nodes.swap(next);
+    }
+    for (size_t n = 0; n < nodes.size(); ++n)
+        for (int r : nodes[n]) t.code[(size_t)r] = (int)n;
+    return t;
+}
+
+}  // namespace
+
 extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, const double* y,
                                   int32_t t, int32_t device, sknnr_index** out) {
     if (!out) return fail(SKNNR_ERR_INVALID, "out is NULL");
@@ -562,67 +693,107 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
             }
         }
 
+        // One 32-reference tile of an image: hi / lo fragments in MFMA A-fragment order and the |r'|^2 block in
+        // accumulator order, for the rows order[32 tile .. 32 tile + 31]
+        auto fill_tile = [&](const std::vector<int>& order, long tile, uint16_t* frag_hi, uint16_t* frag_lo, float* ci) {
+            for (int step = 0; step < ks; ++step)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const long pos = tile * 32 + (lane & 31);
+                    const long row = pos < n_ref ? order[(size_t)pos] : -1;
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = step * 16 + 8 * (lane >> 5) + j;
+                        double a = 0.0;
+                        if (row >= 0 && k < d) a = -2.0 * s * (ref[row * d + k] - ix->mu[k]);
+                        const uint16_t hi = f64_to_f16_bits(a);
+                        frag_hi[((size_t)step * 64 + lane) * 8 + j] = hi;
+                        frag_lo[((size_t)step * 64 + lane) * 8 + j] = f64_to_f16_bits(a - f16_bits_to_f64(hi));
+                    }
+                }
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const long pos = tile * 32 + acc_row(r, h);
+                    ci[h * 16 + r] = pos < n_ref ? (float)cnorm[(size_t)order[(size_t)pos]] : std::numeric_limits<float>::infinity();
+                }
+        };
+        double ymax2 = 0.0;
+        for (int64_t i = 0; i < n_ref; ++i) ymax2 = std::max(ymax2, cnorm[(size_t)i]);
+        ix->ymax = std::sqrt(ymax2);
+
         const int tps = tiles_per_stage(ks);
         const long n_tiles = ((n_ref + 31) / 32 + tps - 1) / tps * tps;
         ix->n_stages = (int)(n_tiles / tps);
         const size_t tb = tile_bytes(ks);
         std::vector<char> img(n_tiles * tb);
-        double ymax2 = 0.0;
         for (long tile = 0; tile < n_tiles; ++tile) {
             char* rec = img.data() + tile * tb;
-            uint16_t* frag = reinterpret_cast<uint16_t*>(rec);
-            for (int part = 0; part < 2; ++part)
-                for (int step = 0; step < ks; ++step)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const long pos = tile * 32 + (lane & 31);
-                        const long row = pos < n_ref ? perm[(size_t)pos] : -1;
-                        for (int j = 0; j < 8; ++j) {
-                            const int k = step * 16 + 8 * (lane >> 5) + j;
-                            double a = 0.0;
-                            if (row >= 0 && k < d) a = -2.0 * s * (ref[row * d + k] - ix->mu[k]);
-                            const uint16_t hi = f64_to_f16_bits(a);
-                            uint16_t bits = hi;
-                            if (part == 1) bits = f64_to_f16_bits(a - f16_bits_to_f64(hi));
-                            frag[((size_t)(part * ks + step) * 64 + lane) * 8 + j] = bits;
-                        }
-                    }
-            float* ci = reinterpret_cast<float*>(rec + tile_frag_bytes(ks));
-            for (int h = 0; h < 2; ++h)
-                for (int r = 0; r < 16; ++r) {
-                    const long pos = tile * 32 + acc_row(r, h);
-                    float v = std::numeric_limits<float>::infinity();
-                    if (pos < n_ref) {
-                        const double yn = cnorm[(size_t)perm[(size_t)pos]];
-                        ymax2 = std::max(ymax2, yn);
-                        v = (float)yn;
-                    }
-                    ci[h * 16 + r] = v;
-                }
+            fill_tile(perm, tile, reinterpret_cast<uint16_t*>(rec), reinterpret_cast<uint16_t*>(rec + (size_t)ks * 1024),
+                      reinterpret_cast<float*>(rec + tile_frag_bytes(ks)));
         }
-        ix->ymax = std::sqrt(ymax2);
         if (ks <= 4) {
             // second-generation kernel: hi fragments + |r'|^2 per tile (staged through LDS), lo fragments in an
             // array of their own (read from L2 by the flush only)
             const int tps2 = tiles_per_stage2(ks);
             const long n_tiles2 = ((n_ref + 31) / 32 + tps2 - 1) / tps2 * tps2;
             ix->n_stages2 = (int)(n_tiles2 / tps2);
+            // ... in CELL order when the kernel will serve this index (bucket.hip.h): rows sorted by the cell of a
+            // median-split tree over the leading principal axes (inside a cell: by centred norm), so that a workgroup
+            // whose query rows were bucketed by the same tree starts its sweep among their neighbours
+            std::vector<int> perm2(perm);
+            int depth = 0;
+            {
+                const char* e = std::getenv("SKNNR_CELLS");
+                int want = e ? std::atoi(e) : kCellMaxDepth;
+                want = std::min(want, std::min(kCellMaxDepth, (int)d));
+                while (want > 0 && (n_ref >> want) < 512) --want;  // cells of at least 512 rows (one 16-tile stage)
+                if (n_tiles2 >= 2 * kSeedTiles && want >= 2) depth = want;
+            }
+            if (depth > 0) {
+                const CellTree tree = build_cell_tree(ref, n_ref, d, ix->mu, depth);
+                for (int64_t i = 0; i < n_ref; ++i) perm2[(size_t)i] = (int)i;
+                // (inside a cell: a fixed pseudo-random order -- sorted by norm, a query's nearest rows would share a few
+                //  tiles and overflow the per-lane hit queues there)
+                auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
+                const bool by_norm = std::getenv("SKNNR_CELL_NORM_ORDER") != nullptr;
+                std::stable_sort(perm2.begin(), perm2.end(), [&](int a, int b) {
+                    if (tree.code[(size_t)a] != tree.code[(size_t)b]) return tree.code[(size_t)a] < tree.code[(size_t)b];
+                    if (by_norm) return cnorm[(size_t)a] < cnorm[(size_t)b];
+                    return mix((uint32_t)a) < mix((uint32_t)b);
+                });
+                const int n_cells = 1 << depth;
+                std::vector<long> first((size_t)n_cells + 1, n_ref);
+                for (int64_t pos = n_ref - 1; pos >= 0; --pos) first[(size_t)tree.code[(size_t)perm2[(size_t)pos]]] = pos;
+                for (int c = n_cells - 1; c >= 0; --c)
+                    if (first[(size_t)c] == n_ref) first[(size_t)c] = first[(size_t)c + 1];  // empty cell: its successor's place
+                std::vector<int> stage((size_t)n_cells);
+                for (int c = 0; c < n_cells; ++c) {
+                    // the seed window (kSeedTiles tiles) is centred on the cell
+                    const long mid_tile = (first[(size_t)c] + first[(size_t)c + 1]) / 2 / 32;
+                    long st = (mid_tile - kSeedTiles / 2) / tps2;
+                    if (mid_tile - kSeedTiles / 2 < 0) st = ix->n_stages2 + (mid_tile - kSeedTiles / 2 - tps2 + 1) / tps2;
+                    stage[(size_t)c] = (int)(((st % ix->n_stages2) + ix->n_stages2) % ix->n_stages2);
+                }
+                HIP_TRY(ix->cell_axes.ensure(tree.axes.size()));
+                HIP_TRY(hipMemcpy(ix->cell_axes.p, tree.axes.data(), tree.axes.size() * sizeof(float), hipMemcpyHostToDevice));
+                HIP_TRY(ix->cell_centre.ensure(tree.centre.size()));
+                HIP_TRY(hipMemcpy(ix->cell_centre.p, tree.centre.data(), tree.centre.size() * sizeof(float), hipMemcpyHostToDevice));
+                HIP_TRY(ix->cell_thr.ensure(tree.thr.size()));
+                HIP_TRY(hipMemcpy(ix->cell_thr.p, tree.thr.data(), tree.thr.size() * sizeof(float), hipMemcpyHostToDevice));
+                HIP_TRY(ix->cell_stage.ensure(stage.size()));
+                HIP_TRY(hipMemcpy(ix->cell_stage.p, stage.data(), stage.size() * sizeof(int), hipMemcpyHostToDevice));
+                HIP_TRY(ix->cell_hist.ensure(2 * kCellMax));
+                ix->cell_depth = depth;
+            }
             const size_t tb2 = tile2_bytes(ks), lob = (size_t)ks * 1024;
             std::vector<char> hi2(n_tiles2 * tb2, 0), lo2(n_tiles2 * lob, 0);
-            for (long tile = 0; tile < n_tiles2; ++tile) {
-                float* c2 = reinterpret_cast<float*>(hi2.data() + tile * tb2 + lob);
-                if (tile < n_tiles) {
-                    const char* rec = img.data() + tile * tb;
-                    std::memcpy(hi2.data() + tile * tb2, rec, lob);
-                    std::memcpy(lo2.data() + tile * lob, rec + lob, lob);
-                    std::memcpy(c2, rec + tile_frag_bytes(ks), 128);
-                } else {
-                    for (int i = 0; i < 32; ++i) c2[i] = std::numeric_limits<float>::infinity();
-                }
-            }
+            for (long tile = 0; tile < n_tiles2; ++tile)
+                fill_tile(perm2, tile, reinterpret_cast<uint16_t*>(hi2.data() + tile * tb2),
+                          reinterpret_cast<uint16_t*>(lo2.data() + tile * lob), reinterpret_cast<float*>(hi2.data() + tile * tb2 + lob));
             HIP_TRY(ix->rhi2.ensure(hi2.size()));
             HIP_TRY(hipMemcpy(ix->rhi2.p, hi2.data(), hi2.size(), hipMemcpyHostToDevice));
             HIP_TRY(ix->rlo2.ensure(lo2.size()));
             HIP_TRY(hipMemcpy(ix->rlo2.p, lo2.data(), lo2.size(), hipMemcpyHostToDevice));
+            HIP_TRY(ix->perm2.ensure((size_t)n_ref));
+            HIP_TRY(hipMemcpy(ix->perm2.p, perm2.data(), (size_t)n_ref * sizeof(int), hipMemcpyHostToDevice));
         }
         {
             double m2 = 0.0;
@@ -824,8 +995,9 @@ extern "C" int sknnr_get_stats(const sknnr_index* cix, sknnr_stats* out) {
     {
         unsigned long long c[8] = {};
         (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(sknnr::coarse_timers), sizeof c);
-        static const char* names[8] = {"operands_wait", "main_no_visit", "main_then_visit", "correct_and_scan", "flush",
-                                       "loop_overhead", "barrier", "wave_total"};
+        // (first kernel: operands_wait, main_no_visit, main_then_visit, correct_and_scan, flush, loop_overhead, barrier;
+        //  second kernel, below: slots 0-4)
+        static const char* names[8] = {"sweep", "visit_scan", "flush", "stage_barrier", "seeding", "-", "-", "wave_total"};
         for (int i = 0; i < 8; ++i)
             std::fprintf(stderr, "[coarse-time] %-18s %14llu  %5.1f %%\n", names[i], c[i], 100.0 * (double)c[i] / (double)(c[7] ? c[7] : 1));
         std::memset(c, 0, sizeof c);
@@ -887,9 +1059,12 @@ namespace {
 
 __global__ void add_counter_kernel(const int* __restrict__ cnt, long long* __restrict__ total) { *total += *cnt; }
 
+// `cells`: also name every row's cell (query bucketing); *cells_done tells whether this kernel did (the
+// register-resident one does; otherwise the caller runs cell_assign_kernel on the transformed rows)
 int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool affine, double* xt,
-                hipStream_t st, bool check_finite = false) {
+                hipStream_t st, bool check_finite = false, bool cells = false, bool* cells_done = nullptr) {
     PrepArgs a{};
+    if (cells_done) *cells_done = false;
     a.status = check_finite ? ix->status.p : nullptr;
     a.x = x;
     a.nq = nq;
@@ -909,6 +1084,11 @@ int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool aff
     const size_t lim = 150 * 1024;
     if (ix->ks <= 4 && !std::getenv("SKNNR_PREP_LDS")) {
         // narrow feature spaces: register-resident kernel (no LDS, high occupancy)
+        if (cells && ix->cell_depth > 0) {
+            a.tree = CellTreeDev{ix->cell_axes.p, ix->cell_centre.p, ix->cell_thr.p, ix->cell_depth};
+            a.cell = ix->qcell.p;
+            if (cells_done) *cells_done = true;
+        }
         const dim3 grid((unsigned)(nq_pad / 256)), block(256);
         switch (ix->ks) {
             case 1: prep_queries_direct_kernel<1><<<grid, block, 0, st>>>(a); break;
@@ -964,11 +1144,12 @@ int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStrea
     static_assert(sh <= 160 * 1024, "LDS budget");
     auto kern = coarse2_kernel<KS, M, WAVES>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    // rows [row0, row0 + rows) of the chunk: the kernel numbers its query blocks from its first argument row
+    // positions [row0, row0 + rows) of the chunk (bucketed calls: position -> row through qperm, else the row itself)
+    const bool bucketed = ix->cell_depth > 0;
     kern<<<dim3((unsigned)(rows / QPB)), dim3(WAVES * 64), sh, st>>>(
-        ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p + (size_t)(row0 / 32) * 2 * KS * 64, ix->qnc.p + row0,
-        (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02), M - (kk + 1), ix->cand_val.p + (size_t)row0 * 2 * M,
-        ix->cand_idx.p + (size_t)row0 * 2 * M);
+        ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
+        M - (kk + 1), ix->cand_val.p, ix->cand_idx.p, (int)row0, bucketed ? ix->qperm.p : nullptr,
+        bucketed ? ix->qcell.p : nullptr, bucketed ? ix->cell_stage.p : nullptr, bucketed ? ix->qlo.p : nullptr);
     HIP_TRY(hipGetLastError());
     return SKNNR_OK;
 }
@@ -1222,6 +1403,11 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
         HIP_TRY(ix->qnc.ensure(cap_pad));
     }
+    if (coarse && ix->cell_depth > 0) {
+        HIP_TRY(ix->qcell.ensure((size_t)cap_pad));
+        HIP_TRY(ix->qperm.ensure((size_t)cap_pad));
+        HIP_TRY(ix->qlo.ensure((size_t)(cap_pad / 32) * ix->ks * 64));
+    }
     if (coarse) {
         HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * coarse_list_len(kk)));
         HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * coarse_list_len(kk)));
@@ -1270,8 +1456,10 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         const long n = std::min(chunk, nq - c0);
         const long n_pad = (n + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
         const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
+        const bool bucketed = coarse && ix->cell_depth > 0 && use_coarse2(ix, coarse_list_len(kk));
+        bool cells_done = false;
         if (coarse || affine) {
-            int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st, check_finite);
+            int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st, check_finite, bucketed, &cells_done);
             if (rc) return rc;
         }
         if (!coarse) continue;
@@ -1283,8 +1471,28 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             ct.coarse.emplace_back(e0, e1);
         }
         auto& ev = ct.coarse[ct.coarse_used++];
-        HIP_TRY(hipEventRecord(ev.first, st));
         const bool v2 = use_coarse2(ix, coarse_list_len(kk));
+        if (bucketed) {
+            // cell of every row, rows bucketed by cell: position -> row (bucket.hip.h)
+            CellArgs ca{};
+            ca.xq = xq_call + c0 * ix->d;
+            ca.nq = n;
+            ca.n_pad = n_pad;
+            ca.d = ix->d;
+            ca.depth = ix->cell_depth;
+            ca.axes = ix->cell_axes.p;
+            ca.centre = ix->cell_centre.p;
+            ca.thr = ix->cell_thr.p;
+            ca.cell = ix->qcell.p;
+            ca.hist = ix->cell_hist.p;
+            ca.perm = ix->qperm.p;
+            HIP_TRY(hipMemsetAsync(ix->cell_hist.p, 0, 2 * kCellMax * sizeof(int), st));
+            if (!cells_done) cell_assign_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(ca);
+            cell_count_kernel<<<dim3((unsigned)((n + kBucketBlock - 1) / kBucketBlock)), dim3(kBucketBlock), 0, st>>>(ca);
+            cell_scatter_kernel<<<dim3((unsigned)((n_pad + kBucketBlock - 1) / kBucketBlock)), dim3(kBucketBlock), 0, st>>>(ca);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(ev.first, st));
         if (v2 && !ix->st_side && !std::getenv("SKNNR_NO_SIDE_STREAM")) {
             HIP_TRY(hipStreamCreateWithFlags(&ix->st_side, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
@@ -1308,8 +1516,9 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         f.s.out_idx = d_idx + c0 * o->n_neighbors;
         f.cand_val = ix->cand_val.p;
         f.cand_idx = ix->cand_idx.p;
-        f.perm = ix->perm.p;
+        f.perm = v2 ? ix->perm2.p : ix->perm.p;
         f.qnc = ix->qnc.p;
+        f.qperm = bucketed ? ix->qperm.p : nullptr;
         f.m_list = coarse_list_len(kk);
         f.inv_s2 = 1.0 / (ix->s * ix->s);
         f.s2 = ix->s * ix->s;
@@ -1321,9 +1530,16 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         f.fail_list = ix->fail_list.p;
         f.fail_count = ix->fail_count.p;
         f.fail_base = (int)c0;
-        // rows [r0, r0 + rows) of the chunk (the kernel indexes everything by the row inside its window)
+        // rows [r0, r0 + rows) of the chunk (the kernel indexes everything by the row inside its window); bucketed
+        // calls: POSITIONS [r0, r0 + rows) of the chunk, the kernel maps them to rows of the chunk
         auto finalize_rows = [&](long r0, long rows, hipStream_t s_) {
             FinalizeArgs g = f;
+            if (bucketed) {
+                g.pos0 = r0;
+                g.s.nq = rows;
+                launch_finalize(g, rows, s_);
+                return;
+            }
             g.s.xq = f.s.xq + r0 * ix->d;
             g.s.nq = rows;
             g.s.row_offset = f.s.row_offset + r0;
