@@ -32,7 +32,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden; exactly these declarations are exported. */
 #pragma GCC visibility push(default)
 
-#define SKNNR_ABI_VERSION 3
+#define SKNNR_ABI_VERSION 4
 
 typedef enum sknnr_status {
     SKNNR_OK = 0,
@@ -224,6 +224,35 @@ int sknnr_predict(sknnr_index* index, const double* q, int64_t nq, const sknnr_q
 int sknnr_predict_from_neighbors(sknnr_index* index, const double* dist, const int64_t* idx,
                                  const double* w, int64_t nq, int32_t k, int32_t weight_mode,
                                  double* out_pred, int32_t mem, void* stream);
+
+/* ---- reference-sharded search ------------------------------------------------------------------ */
+
+/*
+ * When the REFERENCE rows are split over several handles (several GPUs), every shard answers every query row and the
+ * per-shard answers are merged -- SURVEY.md section 8e, "alternative"; the reference's analogue is scikit-learn's
+ * parallel-on-Y strategy: per-thread heaps over chunks of Y, then _parallel_on_Y_synchronize
+ * (SKL/metrics/_pairwise_distances_reduction/_argkmin.pyx.tp:200-261), reached from REF _base.py:162-164.
+ *
+ * sknnr_shard_candidates: the n_neighbors nearest rows of THIS handle's reference rows (a shard) as raw candidates:
+ *   out_val (nq, n_neighbors) the formula's values -- squared distances (expanded / direct), the Hamming distance --
+ *   ascending by (value, index); out_idx the shard's row indices + index_offset (the shard's first row in the whole
+ *   reference set).  No self exclusion (exclude_self must be 0: for the X=None path ask for n_neighbors + 1 and let
+ *   the merge drop the row itself), no square root, no reorder.  The shard must hold at least n_neighbors rows.
+ *
+ * sknnr_merge_shards: the ranks' candidate arrays, gathered -- shard_val / shard_idx (n_shards, nq, kk), kk =
+ *   n_neighbors + exclude_self, shard g's block at [g] -- merged into the call's final answer exactly as
+ *   sknnr_kneighbors gives it (smallest (value, index) first, X=None drop, square root, sknnr's reorder).  `index` is a
+ *   handle over ALL reference rows (every rank holds the small float64 copy; the shards split the sweep): a row whose
+ *   merged answer is not unique -- an exact tie across the last slot, which the reference's heap settles by its
+ *   history -- is re-scanned in float64 over all rows on this handle, the same replay of the reference's engine that
+ *   sknnr_kneighbors uses for tied rows, so that a sharded call returns what the unsharded call returns.
+ *   q / opts as for sknnr_kneighbors (q NULL with exclude_self = 1: the rows are reference rows [row_offset, +nq)).
+ */
+int sknnr_shard_candidates(sknnr_index* index, const double* q, int64_t nq, const sknnr_query_opts* opts,
+                           int64_t index_offset, double* out_val, int64_t* out_idx, int32_t mem, void* stream);
+int sknnr_merge_shards(sknnr_index* index, const double* q, int64_t nq, const sknnr_query_opts* opts, int32_t n_shards,
+                       const double* shard_val, const int64_t* shard_idx, double* out_dist, int64_t* out_idx,
+                       int32_t mem, void* stream);
 
 /* ---- streamed query tiles (raster ingestion) ------------------------------------------------ */
 

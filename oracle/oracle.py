@@ -215,6 +215,62 @@ def kneighbors(fit_X, X=None, k: int = 5, formula: str = "expanded",
     return dist, idx
 
 
+def shard_candidates(fit_X_shard, X, kk: int, formula: str = "expanded", index_offset: int = 0):
+    """One reference shard's answer to every query row, as the merge wants it: the kk smallest values of the
+    formula (squared distances) ascending by (value, index), indices + ``index_offset``.  The analogue of one
+    thread's heaps in scikit-learn's parallel-on-Y strategy
+    (SKL/metrics/_pairwise_distances_reduction/_argkmin.pyx.tp:200-236)."""
+    val, idx = argkmin(X, fit_X_shard, kk, formula, squared=True)
+    order = np.lexsort((idx, val), axis=1)
+    return np.take_along_axis(val, order, 1), np.take_along_axis(idx, order, 1) + int(index_offset)
+
+
+def merge_shards(fit_X, X, shard_val, shard_idx, k: int, formula: str = "expanded", deterministic: bool = True,
+                 decimals: int = 10, row_offset: int = 0):
+    """Merge of the shards' candidates into the call's answer (``X`` None: the X=None path, ``shard_val`` then
+    holds k + 1 candidates per shard).  The merged list is the answer when it is unique -- smallest (value, index)
+    first, which is what one heap over all rows returns when no exact tie decides anything -- and a row with a tie
+    across the last slot (seen in the merged list, or possibly hidden behind a shard whose list ends at the
+    boundary value), or, without deterministic ordering, with equal values among its kept rows, or whose own index
+    is not among its k + 1, is answered by the full replay of the reference's heap (``argkmin`` over all rows):
+    SKL/.../_argkmin.pyx.tp:237-261 (_parallel_on_Y_synchronize) has the same structure."""
+    fit_X = _c64(fit_X)
+    self_rows = X is None
+    kk = k + (1 if self_rows else 0)
+    Xq = fit_X[row_offset:row_offset + shard_val.shape[1]] if self_rows else _c64(X)
+    G, nq, _ = shard_val.shape
+    val = np.empty((nq, kk))
+    idx = np.empty((nq, kk), dtype=np.int64)
+    replay = []
+    for q in range(nq):
+        v = shard_val[:, q, :].ravel()
+        i = shard_idx[:, q, :].ravel()
+        order = np.lexsort((i, v))
+        v, i = v[order], i[order]
+        unique = True
+        if formula == "expanded":
+            vk = v[kk - 1]
+            unique = not (len(v) > kk and v[kk] == vk)
+            unique = unique and not any(shard_val[g, q, kk - 1] == vk for g in range(G))  # a full list ending at vk may hide rows
+            if unique and not deterministic:
+                unique = not (np.diff(v[:kk]) == 0).any()
+            if unique and self_rows:
+                unique = bool((i[:kk] == row_offset + q).any())
+        if unique:
+            val[q], idx[q] = v[:kk], i[:kk]
+        else:
+            replay.append(q)
+    if replay:
+        rv, ri = argkmin(Xq[replay], fit_X, kk, formula, squared=True)
+        val[replay], idx[replay] = rv, ri
+    if self_rows:
+        val, idx = drop_self(val, idx, row_offset)
+    dist = np.sqrt(val)
+    if deterministic:
+        dist, idx = deterministic_reorder(dist, idx, decimals, row_offset)
+    return dist, idx, len(replay)
+
+
 def get_weights(dist, weights):
     """SKL/neighbors/_base.py:81-124."""
     if weights in (None, "uniform"):

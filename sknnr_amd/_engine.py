@@ -212,6 +212,55 @@ class KNNEngine:
         self._check_columns(X, apply_affine)
         return self._index.predict_host(X, opts)
 
+    # ---- reference-sharded search (sknnr_amd.distributed.RefShardedKNN) ------------------------------------
+    def shard_candidates(self, X, kk, *, formula="expanded", apply_affine=False, index_offset=0, check_finite=False):
+        """This engine's rows are one SHARD of a reference set: the ``kk`` nearest of them for every row of ``X`` as raw
+        candidates -- values of the formula (squared distances) ascending by (value, index), indices +
+        ``index_offset`` -- numpy in / numpy out or torch.cuda in / torch.cuda out."""
+        opts = self._opts(kk, exclude_self=False, deterministic=False, decimals=10, formula=formula,
+                          apply_affine=apply_affine, check_finite=check_finite)
+        if is_torch_cuda_tensor(X):
+            import torch
+
+            X = self._as_device_rows(X, apply_affine)
+            nq = X.shape[0]
+            val = torch.empty((nq, kk), dtype=torch.float64, device=X.device)
+            idx = torch.empty((nq, kk), dtype=torch.int64, device=X.device)
+            if nq:
+                stream = torch.cuda.current_stream(X.device).cuda_stream
+                self._index.shard_candidates_device(X.data_ptr(), nq, opts, index_offset, val.data_ptr(), idx.data_ptr(), stream)
+                if check_finite:
+                    self._index.check_finite(stream)
+            return val, idx
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self._check_columns(X, apply_affine)
+        return self._index.shard_candidates_host(X, opts, index_offset)
+
+    def merge_shards(self, X, k, shard_val, shard_idx, *, exclude_self=False, deterministic=True, decimals=10,
+                     formula="expanded", apply_affine=False, row_offset=0, n_self_rows=None):
+        """Merge the gathered candidates ``(n_shards, nq, k + exclude_self)`` of all shards into the call's final
+        ``(dist, idx)``; this engine holds ALL reference rows and re-scans the rows whose merged answer is not unique."""
+        opts = self._opts(k, exclude_self=exclude_self, deterministic=deterministic, decimals=decimals, formula=formula,
+                          apply_affine=apply_affine and X is not None, row_offset=row_offset)
+        if is_torch_cuda_tensor(shard_val):
+            import torch
+
+            n_shards, nq = shard_val.shape[0], shard_val.shape[1]
+            Xd = None if X is None else self._as_device_rows(X, apply_affine)
+            dist = torch.empty((nq, k), dtype=torch.float64, device=shard_val.device)
+            idx = torch.empty((nq, k), dtype=torch.int64, device=shard_val.device)
+            sv, si = shard_val.contiguous(), shard_idx.contiguous()
+            if nq:
+                stream = torch.cuda.current_stream(shard_val.device).cuda_stream
+                self._index.merge_shards_device(0 if Xd is None else Xd.data_ptr(), nq, opts, n_shards, sv.data_ptr(),
+                                                si.data_ptr(), dist.data_ptr(), idx.data_ptr(), stream)
+            return dist, idx
+        nq = shard_val.shape[1] if X is None else None
+        if X is not None:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            self._check_columns(X, apply_affine)
+        return self._index.merge_shards_host(X, opts, shard_val, shard_idx, nq=nq)
+
     def open_stream(self, k, *, weights=None, want_dist=True, deterministic=True, decimals=10,
                     formula="expanded", apply_affine=False, row_offset=0, check_finite=False):
         """A :class:`sknnr_amd._native.QueryStream` over host tiles: ``push(tile)`` keeps the PCIe

@@ -31,7 +31,7 @@ ERR_UNSUPPORTED = -4
 ERR_HIP = -5
 ERR_NO_DEVICE = -6
 ERR_NONFINITE = -7
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/sknnr_hip.h declares (checked by tests/test_cabi.py)
 EXPORTED_SYMBOLS = (
@@ -50,6 +50,8 @@ EXPORTED_SYMBOLS = (
     "sknnr_kneighbors",
     "sknnr_predict",
     "sknnr_predict_from_neighbors",
+    "sknnr_shard_candidates",
+    "sknnr_merge_shards",
     "sknnr_stream_begin",
     "sknnr_stream_push",
     "sknnr_stream_flush",
@@ -156,6 +158,8 @@ def load(build_if_missing: bool = False):
     lib.sknnr_predict.argtypes = [vp, vp, c_int64, POINTER(QueryOpts), vp, vp, vp, c_int32, vp]
     lib.sknnr_predict_from_neighbors.argtypes = [vp, vp, vp, vp, c_int64, c_int32, c_int32, vp,
                                                  c_int32, vp]
+    lib.sknnr_shard_candidates.argtypes = [vp, vp, c_int64, POINTER(QueryOpts), c_int64, vp, vp, c_int32, vp]
+    lib.sknnr_merge_shards.argtypes = [vp, vp, c_int64, POINTER(QueryOpts), c_int32, vp, vp, vp, vp, c_int32, vp]
     lib.sknnr_crosswalk.argtypes = [vp, c_int64, vp, c_int64, vp, c_int32, c_int32, vp]
     lib.sknnr_debug_coarse_matrix.argtypes = [vp, vp, c_int64, vp, vp, POINTER(c_double),
                                               POINTER(c_double)]
@@ -309,6 +313,39 @@ class Index:
         check(load().sknnr_predict_from_neighbors(
             self.handle, c_void_p(dist_ptr or None), c_void_p(idx_ptr), c_void_p(w_ptr or None), nq, k,
             int(weight_mode), c_void_p(pred_ptr), MEM_DEVICE, c_void_p(stream or None)))
+
+    # ---- reference-sharded search (include/sknnr_hip.h) -------------------------------------------
+    def shard_candidates_host(self, q, opts: QueryOpts, index_offset=0):
+        q = _c_f64(q)
+        nq, k = q.shape[0], opts.n_neighbors
+        val = np.empty((nq, k), dtype=np.float64)
+        idx = np.empty((nq, k), dtype=np.int64)
+        check(load().sknnr_shard_candidates(self.handle, _host_ptr(q), nq, byref(opts), int(index_offset),
+                                            _host_ptr(val), _host_ptr(idx), MEM_HOST, None))
+        return val, idx
+
+    def shard_candidates_device(self, q_ptr, nq, opts: QueryOpts, index_offset, val_ptr, idx_ptr, stream=0):
+        check(load().sknnr_shard_candidates(self.handle, c_void_p(q_ptr), nq, byref(opts), int(index_offset),
+                                            c_void_p(val_ptr), c_void_p(idx_ptr), MEM_DEVICE, c_void_p(stream or None)))
+
+    def merge_shards_host(self, q, opts: QueryOpts, shard_val, shard_idx, nq=None, return_distance=True):
+        q = _c_f64(q)
+        shard_val = _c_f64(shard_val)
+        shard_idx = np.ascontiguousarray(shard_idx, dtype=np.int64)
+        n_shards = shard_val.shape[0]
+        if q is not None:
+            nq = q.shape[0]
+        k = opts.n_neighbors
+        idx = np.empty((nq, k), dtype=np.int64)
+        dist = np.empty((nq, k), dtype=np.float64) if return_distance else None
+        check(load().sknnr_merge_shards(self.handle, _host_ptr(q), nq, byref(opts), n_shards, _host_ptr(shard_val),
+                                        _host_ptr(shard_idx), _host_ptr(dist), _host_ptr(idx), MEM_HOST, None))
+        return dist, idx
+
+    def merge_shards_device(self, q_ptr, nq, opts: QueryOpts, n_shards, val_ptr, sidx_ptr, dist_ptr, idx_ptr, stream=0):
+        check(load().sknnr_merge_shards(self.handle, c_void_p(q_ptr or None), nq, byref(opts), n_shards, c_void_p(val_ptr),
+                                        c_void_p(sidx_ptr), c_void_p(dist_ptr or None), c_void_p(idx_ptr), MEM_DEVICE,
+                                        c_void_p(stream or None)))
 
     # ---- diagnostics ------------------------------------------------------------------------
     def debug_coarse_matrix(self, q):

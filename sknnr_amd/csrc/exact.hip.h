@@ -354,6 +354,11 @@ struct SelectArgs {
     long row_offset;       // global row of query 0 of this launch
     const double* hw;      // formula 2 (weighted Hamming): (d) weights
     double hw_sum;         // ... and their sum in index order (what scipy divides by)
+    // Raw candidates of one reference shard (sknnr_shard_candidates): the kk smallest values ascending by
+    // (value, index), squared distances as the formula gives them, indices + id_offset; no self exclusion, no
+    // square root, no reorder.
+    int raw;
+    long id_offset;
     double* out_dist;      // (nq, k) or null
     long* out_idx;         // (nq, k)
 };
@@ -612,7 +617,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         const bool has_next = c + 1 < LPQ;
         const bool tied_here = has_next && by_rank == next && by_rank < INFINITY &&
                                (s.deterministic ? c == s.kk - 1 : c < s.kk);  // across the boundary / involving a kept row
-        if (group_any<LPQ>(tied_here, gbase)) certified = false;
+        // (raw shard candidates are listed by (value, index); which of the rows tied at a shard's last slot it lists is
+        //  settled by the merge, which sees that the shard's list is full and ends at the boundary value)
+        if (!s.raw && group_any<LPQ>(tied_here, gbase)) certified = false;
     }
 
     // X=None: drop the row's own index, or the first entry when it is absent
@@ -626,7 +633,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         sel = rank == drop ? -1 : (rank > drop ? rank - 1 : rank);
     }
     const bool chosen = usable && sel >= 0 && sel < s.k;
-    const double dist = sqrt(d2 > 0.0 ? d2 : 0.0);
+    const double dist = s.raw ? d2 : sqrt(d2 > 0.0 ? d2 : 0.0);
 
     int pos = sel;
     if (s.deterministic) {
@@ -661,7 +668,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     }
     if (live && chosen) {
         if (s.out_dist) s.out_dist[q * s.k + pos] = dist;
-        s.out_idx[q * s.k + pos] = id;
+        s.out_idx[q * s.k + pos] = id + s.id_offset;
     }
     if (live && c == 0 && !certified) {
         const int slot = atomicAdd(a.fail_count, 1);
@@ -805,6 +812,27 @@ __device__ void dual_quicksort_ref(double* v0, int* x0, int n0, int* stack) {
 template <int FORMULA>
 __device__ void scan_finish_query(const SelectArgs& s, long q, double* hv, int* hi, int* stack) {
     const int KK = s.kk;
+    if (s.raw) {
+        // shard candidates: ascending by (value, index) -- an insertion sort of the heap array (formulas 1 and 2 keep
+        // their lists in that order already) -- values and indices as they are
+        for (int e = 1; e < KK; ++e) {
+            const double dv = hv[e];
+            const int iv = hi[e];
+            int jj = e - 1;
+            while (jj >= 0 && (hv[jj] > dv || (hv[jj] == dv && hi[jj] > iv))) {
+                hv[jj + 1] = hv[jj];
+                hi[jj + 1] = hi[jj];
+                --jj;
+            }
+            hv[jj + 1] = dv;
+            hi[jj + 1] = iv;
+        }
+        for (int e = 0; e < s.k; ++e) {
+            if (s.out_dist) s.out_dist[q * s.k + e] = hv[e];
+            s.out_idx[q * s.k + e] = (long)hi[e] + s.id_offset;
+        }
+        return;
+    }
     if (FORMULA == 0) dual_quicksort_ref(hv, hi, KK, stack);
     const long self_id = s.row_offset + q;
     int drop = -1;
@@ -1107,14 +1135,16 @@ __global__ void __launch_bounds__(kScanWaves * 64, SKNNR_SCAN_WPS) exact_scan_ke
 // value (seen, or possibly dropped inside a full slice), with non-deterministic ordering no equal values among
 // the kept rows, and with X=None the row itself among them; every other query goes to list2 for the sequential
 // scan.
+// (forced_slices > 0: the slices are the candidate lists of that many reference SHARDS -- other handles, other GPUs --
+//  laid out the same way: sknnr_merge_shards)
 template <int FORMULA>
-__global__ void __launch_bounds__(256) scan_merge_kernel(ScanArgs a, int grid_wg_of_scan) {
+__global__ void __launch_bounds__(256) scan_merge_kernel(ScanArgs a, int grid_wg_of_scan, int forced_slices) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const SelectArgs& s = a.s;
     const int KK = s.kk;
     const long n_items = a.list ? (long)*a.count : s.nq;
-    const int S = scan_slices(n_items, scan_nq(FORMULA), s.n_ref, KK, grid_wg_of_scan);
-    if (S == 1) return;
+    const int S = forced_slices > 0 ? forced_slices : scan_slices(n_items, scan_nq(FORMULA), s.n_ref, KK, grid_wg_of_scan);
+    if (S == 1 && forced_slices <= 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long slot = (long)blockIdx.x * 4 + wave;
     if (slot >= n_items || lane != 0) return;
@@ -1287,6 +1317,23 @@ __global__ void __launch_bounds__(256) predict_kernel(PredictArgs a) {
     const double num = np_sum(a.k, [&](int i) { return a.y[ids[i] * a.t + tt] * weight(i); });
     const double den = np_sum(a.k, [&](int i) { return weight(i); });
     a.out[e] = num / den;
+}
+
+// Candidate lists of G shards, (G, nq, kk) float64 values and int64 indices as the ranks' all-gather delivers them,
+// into the merge kernel's layout [query][G][kk] (indices as int: a reference set has fewer than 2^31 rows).
+__global__ void __launch_bounds__(256)
+pack_shards_kernel(const double* __restrict__ val, const long* __restrict__ idx, long nq, int g_count, int kk,
+                   double* __restrict__ slice_v, int* __restrict__ slice_i) {
+    const long total = nq * g_count * kk;
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+        const long q = o / ((long)g_count * kk);
+        const int r = (int)(o - q * (long)g_count * kk);
+        const int g = r / kk, e = r - g * kk;
+        const long src = ((long)g * nq + q) * kk + e;
+        slice_v[o] = val[src];
+        slice_i[o] = (int)idx[src];
+    }
 }
 
 __global__ void __launch_bounds__(256)

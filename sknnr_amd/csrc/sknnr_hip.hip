@@ -1304,7 +1304,7 @@ int launch_scan_formula(sknnr_index* ix, const ScanArgs& a0, long max_items, boo
     const long sliced_max = std::min<long>(max_items, (long)kScanGridWg * nq_pass / 2);
     const int kkp = (s.kk + 2) & ~1, stk = (2 * s.kk + 4 + 1) & ~1;
     const size_t msh = 4 * ((size_t)12 * kkp + (size_t)4 * stk);
-    scan_merge_kernel<FORMULA><<<dim3((unsigned)((sliced_max + 3) / 4)), dim3(256), msh, st>>>(a, (int)blocks);
+    scan_merge_kernel<FORMULA><<<dim3((unsigned)((sliced_max + 3) / 4)), dim3(256), msh, st>>>(a, (int)blocks, 0);
     HIP_TRY(hipGetLastError());
     // queries whose merged heaps are not unique (exact ties): the sequential scan, never sliced
     ScanArgs b = a0;
@@ -1376,8 +1376,10 @@ int validate_call(sknnr_index* ix, const double* q, int64_t nq, const sknnr_quer
 }
 
 // Device-resident core: nq rows at xdev (raw if affine else transformed), outputs on device.
+// raw / id_offset: shard candidates (sknnr_shard_candidates): squared values ascending by (value, index), indices +
+// id_offset, no post-steps
 int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_opts* o, double* d_dist,
-               long* d_idx, hipStream_t st) {
+               long* d_idx, hipStream_t st, int raw = 0, long id_offset = 0) {
     const int kk = o->n_neighbors + (o->exclude_self ? 1 : 0);
     const bool affine = o->apply_affine != 0 && xdev != nullptr;
     const bool self_rows = xdev == nullptr;
@@ -1432,6 +1434,9 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     call.row_offset = o->row_offset;
     call.hw = ix->hw.p;
     call.hw_sum = ix->hw_sum;
+    call.raw = raw;
+    call.id_offset = id_offset;
+    if (raw) call.deterministic = 0;
     call.out_dist = d_dist;
     call.out_idx = d_idx;
 
@@ -1844,6 +1849,172 @@ extern "C" int sknnr_kneighbors(sknnr_index* ix, const double* q, int64_t nq, co
     if (mem == SKNNR_MEM_DEVICE) return run_device(ix, q, nq, o, out_dist, (long*)out_idx, (hipStream_t)stream);
     if (q) return run_host_pipeline(ix, q, nq, o, out_dist, (long*)out_idx, nullptr);
     return run_self_rows(ix, nq, o, out_dist, (long*)out_idx, nullptr);
+}
+
+
+// ----------------------------------------------------------------------------------------
+// reference-sharded search: per-shard candidates, then the merge
+// ----------------------------------------------------------------------------------------
+extern "C" int sknnr_shard_candidates(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o,
+                                      int64_t index_offset, double* out_val, int64_t* out_idx, int32_t mem, void* stream) {
+    int rc = validate_call(ix, q, nq, o, out_idx);
+    if (rc) return rc;
+    if (!q || o->exclude_self)
+        return fail(SKNNR_ERR_INVALID, "shard candidates are searched for given rows: the caller adds the self slot (n_neighbors + 1) and the merge drops it");
+    if (!out_val && nq > 0) return fail(SKNNR_ERR_INVALID, "out_val is NULL");
+    if (index_offset < 0 || index_offset + ix->n_ref > 0x7fffff00L) return fail(SKNNR_ERR_INVALID, "index_offset out of range");
+    if (nq == 0) return SKNNR_OK;
+    if (mem != SKNNR_MEM_DEVICE && mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    std::lock_guard<std::mutex> lock(ix->mtx);
+    HIP_TRY(hipSetDevice(ix->device));
+    if (mem == SKNNR_MEM_DEVICE) return run_device(ix, q, nq, o, out_val, (long*)out_idx, (hipStream_t)stream, 1, index_offset);
+    // host buffers: one staged round trip (a shard's candidates are an intermediate of a multi-GPU call, not a hot host path)
+    const int k = o->n_neighbors;
+    const int d_x = o->apply_affine ? ix->d_in : ix->d;
+    DevBuf<double> dq, dv;
+    DevBuf<long> di;
+    HIP_TRY(dq.ensure((size_t)nq * d_x));
+    HIP_TRY(dv.ensure((size_t)nq * k));
+    HIP_TRY(di.ensure((size_t)nq * k));
+    HIP_TRY(hipMemcpy(dq.p, q, (size_t)nq * d_x * sizeof(double), hipMemcpyHostToDevice));
+    rc = run_device(ix, dq.p, nq, o, dv.p, di.p, nullptr, 1, index_offset);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (o->check_finite && (rc = poll_status(ix))) return rc;
+    HIP_TRY(hipMemcpy(out_val, dv.p, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_idx, di.p, (size_t)nq * k * sizeof(long), hipMemcpyDeviceToHost));
+    return SKNNR_OK;
+}
+
+namespace {
+
+template <int FORMULA>
+int merge_shards_formula(sknnr_index* ix, const SelectArgs& call, int n_shards, long nq, hipStream_t st) {
+    ScanArgs a{call, ix->refT.p, nullptr, nullptr, ix->slice_v.p, ix->slice_i.p, ix->fail_list2.p, ix->fail_count.p + 2};
+    const int kkp = (call.kk + 2) & ~1, stk = (2 * call.kk + 4 + 1) & ~1;
+    const size_t msh = 4 * ((size_t)12 * kkp + (size_t)4 * stk);
+    scan_merge_kernel<FORMULA><<<dim3((unsigned)((nq + 3) / 4)), dim3(256), msh, st>>>(a, 0, n_shards);
+    HIP_TRY(hipGetLastError());
+    // rows whose merged answer is not unique (exact ties that the reference's heap settles by its history): the
+    // sequential scan over ALL reference rows of this handle, as for any other tied row
+    const size_t sh = scan_block_bytes(call.d, call.kk, call.formula);
+    if (sh > 150 * 1024) return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", call.k, call.d);
+    ScanArgs b{call, ix->refT.p, ix->fail_list2.p, ix->fail_count.p + 2, nullptr, nullptr, nullptr, nullptr};
+    const bool chunked = call.d > kScanColChunk;
+    auto kern = chunked ? exact_scan_kernel<FORMULA, true> : exact_scan_kernel<FORMULA, false>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    constexpr int nq_pass = scan_nq(FORMULA);
+    const long blocks = std::max<long>(1, std::min<long>((nq + nq_pass - 1) / nq_pass, kScanGridWg));
+    kern<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(b);
+    HIP_TRY(hipGetLastError());
+    return SKNNR_OK;
+}
+
+// Device-resident core of sknnr_merge_shards.
+int merge_shards_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_opts* o, int n_shards,
+                        const double* shard_val, const long* shard_idx, double* d_dist, long* d_idx, hipStream_t st) {
+    const int kk = o->n_neighbors + (o->exclude_self ? 1 : 0);
+    const bool affine = o->apply_affine != 0 && xdev != nullptr;
+    const bool self_rows = xdev == nullptr;
+    if (nq > 0x7fffffffL) return fail(SKNNR_ERR_UNSUPPORTED, "more than 2^31 - 1 query rows in one call");
+    if (affine && ix->ks == 0) return fail(SKNNR_ERR_UNSUPPORTED, "d = %d > 128 with an affine map is outside the HIP envelope", ix->d);
+    if (ix->ws_busy) HIP_TRY(hipStreamWaitEvent(st, ix->ev_ws, 0));
+    // the transformed rows (the tied rows are re-scanned in them)
+    const double* xq_call = self_rows ? ix->ref64.p + o->row_offset * ix->d : xdev;
+    if (affine) {
+        HIP_TRY(ix->xt.ensure((size_t)nq * ix->d));
+        const long chunk = chunk_rows(ix->ks, 2);
+        const long cap_pad = (std::min(chunk, nq) + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
+        HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
+        HIP_TRY(ix->qnc.ensure(cap_pad));
+        for (long c0 = 0; c0 < nq; c0 += chunk) {
+            const long n = std::min(chunk, nq - c0);
+            const long n_pad = (n + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
+            int rc = launch_prep(ix, xdev + c0 * ix->d_in, n, n_pad, true, ix->xt.p + c0 * ix->d, st, o->check_finite != 0);
+            if (rc) return rc;
+        }
+        xq_call = ix->xt.p;
+    }
+    SelectArgs call{};
+    call.xq = xq_call;
+    call.ref = ix->ref64.p;
+    call.rn = ix->rn64.p;
+    call.nq = nq;
+    call.d = ix->d;
+    call.n_ref = (int)ix->n_ref;
+    call.k = o->n_neighbors;
+    call.kk = kk;
+    call.exclude_self = o->exclude_self ? 1 : 0;
+    call.deterministic = o->deterministic ? 1 : 0;
+    call.formula = o->formula;
+    call.pow10_is_divisor = o->decimals < 0;
+    call.pow10 = std::pow(10.0, std::abs(o->decimals));
+    call.row_offset = o->row_offset;
+    call.hw = ix->hw.p;
+    call.hw_sum = ix->hw_sum;
+    call.out_dist = d_dist;
+    call.out_idx = d_idx;
+    const size_t heaps = (size_t)nq * n_shards * kk;
+    HIP_TRY(ix->slice_v.ensure(heaps));
+    HIP_TRY(ix->slice_i.ensure(heaps));
+    HIP_TRY(ix->fail_list2.ensure((size_t)nq));
+    HIP_TRY(hipMemsetAsync(ix->fail_count.p, 0, 16, st));
+    pack_shards_kernel<<<dim3((unsigned)std::min<long>(((long)heaps + 255) / 256, 256L * 32)), dim3(256), 0, st>>>(
+        shard_val, shard_idx, nq, n_shards, kk, ix->slice_v.p, ix->slice_i.p);
+    HIP_TRY(hipGetLastError());
+    int rc;
+    switch (o->formula) {
+        case 0: rc = merge_shards_formula<0>(ix, call, n_shards, nq, st); break;
+        case 1: rc = merge_shards_formula<1>(ix, call, n_shards, nq, st); break;
+        default: rc = merge_shards_formula<2>(ix, call, n_shards, nq, st); break;
+    }
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ix->ev_ws, st));
+    ix->ws_busy = true;
+    ix->stats.queries += nq;
+    ix->stats.exact_only_queries += nq;
+    return SKNNR_OK;
+}
+
+}  // namespace
+
+extern "C" int sknnr_merge_shards(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o, int32_t n_shards,
+                                  const double* shard_val, const int64_t* shard_idx, double* out_dist, int64_t* out_idx,
+                                  int32_t mem, void* stream) {
+    int rc = validate_call(ix, q, nq, o, out_idx);
+    if (rc) return rc;
+    if (n_shards < 1 || n_shards > 64) return fail(SKNNR_ERR_INVALID, "n_shards must be in [1, 64], got %d", n_shards);
+    if ((!shard_val || !shard_idx) && nq > 0) return fail(SKNNR_ERR_INVALID, "shard candidate arrays are NULL");
+    const int kk = o->n_neighbors + (o->exclude_self ? 1 : 0);
+    if (kk > kScanSliceMaxKK) return fail(SKNNR_ERR_UNSUPPORTED, "the shard merge serves n_neighbors (+ self) <= %d", kScanSliceMaxKK);
+    if (nq == 0) return SKNNR_OK;
+    if (mem != SKNNR_MEM_DEVICE && mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    std::lock_guard<std::mutex> lock(ix->mtx);
+    HIP_TRY(hipSetDevice(ix->device));
+    if (mem == SKNNR_MEM_DEVICE)
+        return merge_shards_device(ix, q, nq, o, n_shards, shard_val, (const long*)shard_idx, out_dist, (long*)out_idx, (hipStream_t)stream);
+    const int k = o->n_neighbors;
+    const int d_x = o->apply_affine ? ix->d_in : ix->d;
+    const size_t n_cand = (size_t)nq * n_shards * kk;
+    DevBuf<double> dq, dv, dd;
+    DevBuf<long> dsi, di;
+    if (q) {
+        HIP_TRY(dq.ensure((size_t)nq * d_x));
+        HIP_TRY(hipMemcpy(dq.p, q, (size_t)nq * d_x * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(dv.ensure(n_cand));
+    HIP_TRY(dsi.ensure(n_cand));
+    HIP_TRY(dd.ensure((size_t)nq * k));
+    HIP_TRY(di.ensure((size_t)nq * k));
+    HIP_TRY(hipMemcpy(dv.p, shard_val, n_cand * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dsi.p, shard_idx, n_cand * sizeof(long), hipMemcpyHostToDevice));
+    rc = merge_shards_device(ix, q ? dq.p : nullptr, nq, o, n_shards, dv.p, dsi.p, dd.p, di.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (o->check_finite && q && (rc = poll_status(ix))) return rc;
+    if (out_dist) HIP_TRY(hipMemcpy(out_dist, dd.p, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_idx, di.p, (size_t)nq * k * sizeof(long), hipMemcpyDeviceToHost));
+    return SKNNR_OK;
 }
 
 // ----------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ from typing import Callable
 
 import numpy as np
 
-__all__ = ["shard_bounds", "cyclic_slot", "all_gather_rows", "ShardedKNN"]
+__all__ = ["shard_bounds", "cyclic_slot", "all_gather_rows", "ShardedKNN", "RefShardedKNN"]
 
 
 def shard_bounds(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -298,3 +298,124 @@ class ShardedKNN:
         if on_gpu:
             torch.cuda.current_stream(dev).wait_stream(comm)
         return d_all, i_all
+
+
+class RefShardedKNN:
+    """REFERENCE-row sharding ("alternative"): rank ``r`` sweeps rows ``shard_bounds(n_ref, W, r)``
+    of the reference set for ALL query rows, the ranks all-gather their per-shard candidates ``(value, index)`` --
+    ``k`` (+1 for X=None) pairs per query and shard -- and every rank merges them into the call's answer.  The mode for
+    few queries against a large reference set (the query-row sharding of :class:`ShardedKNN` needs at least a
+    workgroup of rows per GPU to keep them busy).  The reference's analogue is scikit-learn's parallel-on-Y strategy
+    (per-thread heaps over chunks of Y, then ``_parallel_on_Y_synchronize``:
+    SKL/metrics/_pairwise_distances_reduction/_argkmin.pyx.tp:200-261).
+
+    Exactness: the merged list (smallest (value, index) first) is the answer whenever it is unique; rows with an exact
+    tie across the last slot are re-scanned over all reference rows by the full engine every rank holds (the small
+    float64 copy of the rows; only the SWEEP is split), exactly as the unsharded call treats tied rows -- a sharded
+    call returns what the unsharded call returns.
+
+    Parameters
+    ----------
+    estimator : a fitted ``sknnr_amd`` estimator (every rank the same one), or None with the three callables
+    local_candidates : ``f(X, kk, a, b) -> (val (nq, kk), idx (nq, kk))`` candidates of reference rows [a, b)
+    merge : ``f(X, k, shard_val, shard_idx, use_deterministic_ordering) -> (dist, idx)``
+    n_ref : number of reference rows (with the callables)
+    """
+
+    def __init__(self, estimator=None, group=None, local_candidates: Callable | None = None,
+                 merge: Callable | None = None, n_ref: int | None = None):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
+        self.estimator = estimator
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        self._shard_engine = None
+        if estimator is not None:
+            reg = getattr(estimator, "regressor_", estimator)
+            self.n_ref = reg.n_samples_fit_
+        else:
+            if local_candidates is None or merge is None or n_ref is None:
+                raise ValueError("without an estimator, local_candidates, merge and n_ref are required")
+            self.n_ref = int(n_ref)
+        self._local_candidates = local_candidates or self._engine_candidates
+        self._merge = merge or self._engine_merge
+        self.bounds = shard_bounds(self.n_ref, self.world_size, self.rank)
+
+    # ---- the HIP engine as local worker ---------------------------------------------------------
+    def _reg(self):
+        est = self.estimator
+        return getattr(est, "regressor_", est), hasattr(est, "regressor_")
+
+    def _shard(self):
+        """Engine over this rank's rows of the (transformed) reference set, with the estimator's affine map."""
+        if self._shard_engine is None:
+            from ._engine import KNNEngine
+
+            reg, _ = self._reg()
+            a, b = self.bounds
+            eng = KNNEngine(reg._fit_X[a:b], None, device=reg._device)
+            if getattr(reg, "effective_metric_", "euclidean") == "hamming":
+                eng.set_hamming_weights(reg._hamming_w)
+            if reg._affine is not None:
+                eng.set_affine(*reg._affine)
+            self._shard_engine = eng
+        return self._shard_engine
+
+    def _engine_candidates(self, X, kk, a, b):
+        reg, transformed = self._reg()
+        if b - a < kk:
+            raise ValueError(f"rank {self.rank} holds {b - a} reference rows, fewer than the {kk} neighbours asked for")
+        if X is None:  # the X=None path: the queries are the (transformed) reference rows themselves
+            return self._shard().shard_candidates(reg._fit_X, kk, formula=reg._formula(), index_offset=a)
+        return self._shard().shard_candidates(X, kk, formula=reg._formula(), apply_affine=self._device_affine(), index_offset=a,
+                                              check_finite=True)
+
+    def _engine_merge(self, X, k, shard_val, shard_idx, use_deterministic_ordering):
+        reg, transformed = self._reg()
+        return reg.engine_.merge_shards(X, k, shard_val, shard_idx, exclude_self=X is None,
+                                        deterministic=use_deterministic_ordering,
+                                        decimals=reg.DISTANCE_PRECISION_DECIMALS, formula=reg._formula(),
+                                        apply_affine=self._device_affine() and X is not None)
+
+    def _device_affine(self):
+        """Is the estimator's feature map applied on the device (affine spaces) or were the rows mapped on the host
+        (tree-node spaces)?"""
+        _, transformed = self._reg()
+        return transformed and getattr(self.estimator, "_device_affine", True)
+
+    # ---- public -----------------------------------------------------------------------------------
+    def kneighbors(self, X=None, n_neighbors=None, *, use_deterministic_ordering=True):
+        """Neighbours of every row of ``X`` (every rank passes the same rows; ``None``: of every reference row, itself
+        excluded), the reference rows swept shard by shard."""
+        import torch
+        import torch.distributed as dist
+
+        if self.estimator is not None:
+            reg, transformed = self._reg()
+            k = reg._resolve_k(n_neighbors)
+            if X is not None:
+                X = (self.estimator._validate_raw_query(X) if transformed else reg._validate_query(X))
+        else:
+            k = int(n_neighbors)
+        kk = k + (1 if X is None else 0)
+        a, b = self.bounds
+        val, idx = self._local_candidates(X, kk, a, b)
+        as_numpy = isinstance(idx, np.ndarray)
+        tv = val if isinstance(val, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(val))
+        ti = idx if isinstance(idx, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(idx))
+        if dist.get_backend(self.group) == "nccl" and not tv.is_cuda:
+            tv, ti = tv.cuda(), ti.cuda()
+        tv, ti = tv.contiguous(), ti.contiguous()
+        nq = tv.shape[0]
+        all_v = torch.empty((self.world_size * nq, kk), dtype=tv.dtype, device=tv.device)
+        all_i = torch.empty((self.world_size * nq, kk), dtype=ti.dtype, device=ti.device)
+        # one exchange step: every rank contributes (nq, kk) pairs and receives W - 1 such blocks, one per xGMI link
+        dist.all_gather_into_tensor(all_v, tv, group=self.group)
+        dist.all_gather_into_tensor(all_i, ti, group=self.group)
+        all_v, all_i = all_v.view(self.world_size, nq, kk), all_i.view(self.world_size, nq, kk)
+        if as_numpy:
+            all_v, all_i = all_v.cpu().numpy(), all_i.cpu().numpy()
+        return self._merge(X, k, all_v, all_i, use_deterministic_ordering)

@@ -52,7 +52,7 @@ def test_no_other_symbols_leak(native):
 
 def test_abi_version_and_last_error(native):
     lib = native.load()
-    assert lib.sknnr_abi_version() == native.ABI_VERSION == 3
+    assert lib.sknnr_abi_version() == native.ABI_VERSION == 4
     assert isinstance(lib.sknnr_last_error(), bytes)
 
 

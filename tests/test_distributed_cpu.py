@@ -106,6 +106,82 @@ def test_two_rank_sharding_matches_single_call(tmp_path, n_q):
             np.testing.assert_array_equal(r["d_cyc"], dg)
 
 
+def _ref_worker(rank, world, port, out_dir):
+    """Reference-row sharding on CPU: the oracle is each rank's local engine and the merge is the oracle's restatement of
+    the device merge (oracle.merge_shards); the distributed plumbing -- shard bounds, global index offsets, the all-gather
+    layout (shard, row, slot), the k + 1 candidates of the X=None path -- is the product's RefShardedKNN."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from sknnr_amd.distributed import RefShardedKNN
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x_ref, x_q = _ref_sharded_problem()
+        res = {}
+        for formula in ("expanded", "direct"):
+            for det in (True, False):
+                replays = []
+
+                def cand(X, kk, a, b, formula=formula):
+                    Xq = x_ref if X is None else X
+                    return O.shard_candidates(x_ref[a:b], Xq, kk, formula, index_offset=a)
+
+                def merge(X, k, sv, si, use_det, formula=formula, replays=replays):
+                    d, i, n_replay = O.merge_shards(x_ref, X, sv, si, k, formula, deterministic=use_det)
+                    replays.append(n_replay)
+                    return d, i
+
+                sh = RefShardedKNN(None, local_candidates=cand, merge=merge, n_ref=len(x_ref))
+                d, i = sh.kneighbors(x_q, 4, use_deterministic_ordering=det)
+                ds, is_ = sh.kneighbors(None, 4, use_deterministic_ordering=det)
+                tag = f"{formula}_{int(det)}"
+                res.update({f"d_{tag}": d, f"i_{tag}": i, f"ds_{tag}": ds, f"is_{tag}": is_, f"replays_{tag}": np.asarray(replays)})
+        np.savez(os.path.join(out_dir, f"ref_rank{rank}.npz"), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def _ref_sharded_problem():
+    """300 reference rows with exact duplicates placed on BOTH sides of the shard boundaries (rows 150 / 100, 200) and
+    queries that are copies of such rows: ties across the k-th slot whose rows live in different shards."""
+    from sknnr_amd import synth
+
+    x_ref, _, x_q = synth.make_problem(300, 40, 6, t=2, n_dup_refs=0, n_dup_queries=0)
+    for a, b in ((10, 160), (11, 161), (12, 162), (13, 163), (14, 290), (14, 105), (99, 100), (149, 150), (149, 151), (5, 205), (5, 206)):
+        x_ref[b] = x_ref[a]
+    x_q[:8] = x_ref[[10, 14, 99, 149, 5, 160, 206, 290]]   # zero distances, duplicates split across shards
+    x_q[8] = 0.5 * (x_ref[20] + x_ref[170])                  # ordinary rows
+    return x_ref, x_q
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reference_sharded_search_matches_the_unsharded_call(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as O
+
+    mp.spawn(_ref_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    x_ref, x_q = _ref_sharded_problem()
+    for formula in ("expanded", "direct"):
+        for det in (True, False):
+            d, i = O.kneighbors(x_ref, x_q, 4, formula, deterministic=det)
+            ds, is_ = O.kneighbors(x_ref, None, 4, formula, deterministic=det)
+            tag = f"{formula}_{int(det)}"
+            for rank in range(world):
+                r = np.load(os.path.join(str(tmp_path), f"ref_rank{rank}.npz"))
+                np.testing.assert_array_equal(r[f"i_{tag}"], i)
+                np.testing.assert_array_equal(r[f"d_{tag}"], d)
+                np.testing.assert_array_equal(r[f"is_{tag}"], is_)
+                np.testing.assert_array_equal(r[f"ds_{tag}"], ds)
+                if formula == "expanded":
+                    assert r[f"replays_{tag}"].sum() > 0   # the tied rows really took the replay path
+                else:
+                    assert r[f"replays_{tag}"].sum() == 0  # (value, index) order is the direct formula's own rule
+
+
 def test_shard_bounds_partition_the_rows():
     from sknnr_amd.distributed import shard_bounds
 

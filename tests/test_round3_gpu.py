@@ -41,3 +41,118 @@ def test_callable_weights_over_tiles_carry_the_global_row(N):
     np.testing.assert_array_equal(est.predict_chunks(iter(tiles)), whole)
     out = np.empty((16, 3))
     np.testing.assert_array_equal(est.predict_chunks(iter(tiles), out=out), whole)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-sharded search (SURVEY 8e "alternative"; include/sknnr_hip.h: sknnr_shard_candidates / sknnr_merge_shards)
+# ---------------------------------------------------------------------------------------------
+def _sharded(N, x_ref, x_q, k, n_shards, formula, deterministic, self_rows=False, device_mem=False):
+    """Candidates of `n_shards` shard handles, gathered as (shard, row, slot), merged on a handle over all rows."""
+    from sknnr_amd.distributed import shard_bounds
+
+    f = {"expanded": N.FORMULA_EXPANDED, "direct": N.FORMULA_DIRECT}[formula]
+    kk = k + (1 if self_rows else 0)
+    q = x_ref if self_rows else x_q
+    vals, idxs = [], []
+    for g in range(n_shards):
+        a, b = shard_bounds(len(x_ref), n_shards, g)
+        ix = N.Index(x_ref[a:b])
+        v, i = ix.shard_candidates_host(q, ix.make_opts(kk, formula=f, deterministic=False), index_offset=a)
+        assert (np.diff(v, axis=1) >= 0).all() and i.min() >= a and i.max() < b
+        vals.append(v)
+        idxs.append(i)
+        ix.close()
+    full = N.Index(x_ref)
+    o = full.make_opts(k, formula=f, deterministic=deterministic, exclude_self=self_rows)
+    sv, si = np.stack(vals), np.stack(idxs)
+    if device_mem:
+        import torch
+
+        tv, ti = torch.as_tensor(sv, device="cuda"), torch.as_tensor(si, device="cuda")
+        tq = None if self_rows else torch.as_tensor(x_q, device="cuda")
+        dd = torch.empty((len(q), k), dtype=torch.float64, device="cuda")
+        di = torch.empty((len(q), k), dtype=torch.int64, device="cuda")
+        full.merge_shards_device(0 if tq is None else tq.data_ptr(), len(q), o, n_shards, tv.data_ptr(), ti.data_ptr(),
+                                 dd.data_ptr(), di.data_ptr())
+        torch.cuda.synchronize()
+        dist, idx = dd.cpu().numpy(), di.cpu().numpy()
+    else:
+        dist, idx = full.merge_shards_host(None if self_rows else x_q, o, sv, si, nq=len(q))
+    want = full.kneighbors_host(None if self_rows else x_q, o, nq=len(q))
+    full.close()
+    return (dist, idx), want, (sv, si)
+
+
+@pytest.mark.parametrize("formula", ["expanded", "direct"])
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_reference_sharded_search_with_duplicates_across_shards(N, formula, deterministic):
+    """The gloo test's problem (tests/test_distributed_cpu.py: exact duplicates on both sides of the shard boundaries,
+    queries that are copies of them) through the HIP entry points: bit-equal to the oracle's single heap over all rows
+    and to the unsharded HIP call, for given rows and for the X=None path, 2 and 3 shards."""
+    from oracle import oracle as O
+    from test_distributed_cpu import _ref_sharded_problem
+
+    x_ref, x_q = _ref_sharded_problem()
+    for n_shards in (2, 3):
+        for self_rows in (False, True):
+            (dist, idx), (wd, wi), (sv, si) = _sharded(N, x_ref, x_q, 4, n_shards, formula, deterministic, self_rows)
+            od, oi = O.kneighbors(x_ref, None if self_rows else x_q, 4, formula, deterministic=deterministic)
+            np.testing.assert_array_equal(idx, oi)
+            np.testing.assert_array_equal(dist, od)
+            np.testing.assert_array_equal(idx, wi)
+            np.testing.assert_array_equal(dist, wd)
+            # ... and the oracle's restatement of the merge (which the gloo test uses) says the same
+            md, mi, _ = O.merge_shards(x_ref, None if self_rows else x_q, sv, si, 4, formula, deterministic=deterministic)
+            np.testing.assert_array_equal(mi, idx)
+            np.testing.assert_array_equal(md, dist)
+
+
+def test_reference_sharded_search_on_the_mfma_path(N):
+    """Shards large enough for the pre-filter (3 x 6,000 rows x 32 features, a few rows duplicated across shards), 20,000
+    query rows, device memory: candidates come from the MFMA path in raw mode (squared values by (value, index)),
+    the merge equals the unsharded call and the oracle."""
+    from oracle import oracle as O
+    from sknnr_amd import synth
+
+    x_ref, _, x_q = synth.make_problem(18_000, 20_000, 32, t=2, n_dup_queries=32)
+    x_ref[7000:7040] = x_ref[100:140]
+    x_ref[13000:13020] = x_ref[100:120]
+    for k, self_rows in ((5, False), (3, True)):
+        (dist, idx), (wd, wi), _ = _sharded(N, x_ref, x_q, k, 3, "expanded", True, self_rows, device_mem=True)
+        np.testing.assert_array_equal(idx, wi)
+        np.testing.assert_array_equal(dist, wd)
+        od, oi = O.kneighbors(x_ref, None if self_rows else x_q, k, "expanded")
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+
+
+def test_ref_sharded_knn_class_single_rank(tmp_path):
+    """RefShardedKNN over a fitted estimator with one gloo rank on the GPU box: the class's own engine plumbing (shard
+    engine with the estimator's affine map, candidates, all-gather, merge, X=None) against estimator.kneighbors."""
+    import socket
+
+    import torch.distributed as dist
+
+    import sknnr_amd
+    from sknnr_amd import synth
+    from sknnr_amd.distributed import RefShardedKNN
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        x_ref, y, x_q = synth.make_problem(5000, 3000, 16, t=4, kind="positive", n_dup_queries=16)
+        est = sknnr_amd.GNNRegressor(n_neighbors=4).fit(x_ref, y)
+        sh = RefShardedKNN(est)
+        for det in (True, False):
+            d, i = sh.kneighbors(x_q, use_deterministic_ordering=det)
+            wd, wi = est.kneighbors(x_q, use_deterministic_ordering=det)
+            np.testing.assert_array_equal(i, wi)
+            np.testing.assert_array_equal(d, wd)
+        d, i = sh.kneighbors(None)
+        wd, wi = est.kneighbors()
+        np.testing.assert_array_equal(i, wi)
+        np.testing.assert_array_equal(d, wd)
+    finally:
+        dist.destroy_process_group()
