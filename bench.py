@@ -47,8 +47,8 @@ PEAK_HBM_GBS = 8000.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30, help="timed passes (default: ~1.5 s of device time, enough for a 1 Hz SMI sampler to see it)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=10_000_000,
                     help="query rows of the job (strong scaling: in total; weak: per GPU)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
@@ -186,6 +186,37 @@ def baseline_metric():
         return "Mqueries/sec + achieved HBM GB/s, 10M\u00d750k\u00d732 k=5, 1/2/4/8 MI355X"
 
 
+def library_sha16():
+    """First 16 hex digits of the SHA-256 of the loaded HIP library: the committed counter summaries carry the stamp of
+    the build they were measured on and are only quoted for that build."""
+    import hashlib
+
+    from sknnr_amd import _native
+
+    try:
+        with open(_native.library_path(), "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def committed_traffic(n_ref, d_t, k):
+    """HBM bytes per query row from the committed rocprofv3 --pmc passes of this same command (counters cannot be
+    collected inside the process): (dominant kernel, whole step, note), or (None, None, why)."""
+    path = os.path.join(ROOT, "profiles", "r03_coarse_pmc.json")
+    if (n_ref, d_t, k) != (50_000, 32, 5):
+        return None, None, "no committed counter passes for this shape"
+    if not os.path.exists(path):
+        return None, None, "profiles/r03_coarse_pmc.json is missing"
+    pmc = json.load(open(path))
+    if pmc.get("lib_sha16") != library_sha16():
+        return None, None, (f"profiles/r03_coarse_pmc.json was measured on library {pmc.get('lib_sha16')}, this run loads "
+                            f"{library_sha16()}: not quoted")
+    return pmc["hbm_bytes_per_query_row"], pmc.get("step_hbm_bytes_per_query_row"), (
+        "profiles/r03_coarse_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 only for the kernels whose reads are "
+        "wide coalesced: the pre-filter's LDS-DMA stages; WRITE_SIZE as read), same library build, scaled to this step's rows")
+
+
 def mfma_frac(nq, n_ref, d_t, coarse_ms):
     tf = 2.0 * nq * n_ref * d_t / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
     return tf, tf / PEAK_F16_MFMA_TFLOPS
@@ -307,15 +338,9 @@ def main():
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(done)
                 for whole, own in ((d_all[world * a: world * b], d_own), (i_all[world * a: world * b], i_own)):
-                    try:
-                        # in place: the send buffer is this rank's slot of the receive buffer
-                        works.append(dist.all_gather_into_tensor(whole, own if gather_in_place[0] else own.clone(),
-                                                                 async_op=True))
-                    except RuntimeError:
-                        if not gather_in_place[0]:
-                            raise
-                        gather_in_place[0] = False  # a backend that rejects aliasing: stage the slot once
-                        works.append(dist.all_gather_into_tensor(whole, own.clone(), async_op=True))
+                    # in place (the send buffer is this rank's slot of the receive buffer) when the probe below said
+                    # the backend takes it
+                    works.append(dist.all_gather_into_tensor(whole, own if gather_in_place[0] else own.clone(), async_op=True))
         for w in works:
             w.wait()
         torch.cuda.current_stream().wait_stream(comm_stream)
@@ -327,6 +352,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_dist and not args.no_gather:
+        # One probe collective BEFORE the timed region decides whether the all-gather may be in place: a synchronous
+        # refusal and an asynchronous failure (surfacing at wait / synchronize) are both caught here, and every rank
+        # takes the same decision (MIN over ranks).
+        probe = torch.arange(world * 8, dtype=torch.float64, device="cuda").reshape(world * 2, 4)
+        want = probe.clone()
+        ok = 1
+        try:
+            w_ = dist.all_gather_into_tensor(probe, probe[rank * 2: rank * 2 + 2], async_op=True)
+            w_.wait()
+            torch.cuda.synchronize()
+            ok = int(torch.equal(probe, want))
+        except RuntimeError:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_in_place[0] = bool(flag.item())
     for _ in range(args.warmup):
         step()
     barrier()
@@ -354,25 +396,19 @@ def main():
         rows_timed = st["coarse_rows_timed"] / args.steps
         achieved_tf, frac = mfma_frac(rows_timed, args.refs, d_t, coarse_ms)
         alg_bytes = nq * args.dims * 8 + args.refs * d_t * 8 + nq * k * 16
-        traffic, traffic_note = None, None
-        for pmc_name in ("r02_coarse_pmc.json", "r01_coarse_pmc.json"):
-            pmc_file = os.path.join(ROOT, "profiles", pmc_name)
-            if os.path.exists(pmc_file) and (args.refs, d_t, k) == (50_000, 32, 5):
-                # PMC counters cannot be collected inside this process; the committed rocprofv3 --pmc
-                # passes of this same command give HBM bytes per query row for the dominant kernel
-                # (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section), scaled to this step.
-                pmc = json.load(open(pmc_file))
-                traffic = pmc["hbm_bytes_per_query_row"] * rows_timed
-                traffic_note = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE), bytes per step of the "
-                                "timed launches")
-                break
+        per_row, step_per_row, traffic_note = committed_traffic(args.refs, d_t, k)
+        traffic = per_row * rows_timed if per_row is not None else None
+        traffic_step = step_per_row * nq if step_per_row is not None else None
         assert frac <= 1.0, (frac, coarse_ms, st)
         roofline = {
             "kernel": "sknnr::coarse2_kernel<KS=%d,M=%d,WAVES=16> (f16 split MFMA pre-filter: seeded thresholds, main hi.hi products swept on the matrix "
                       "pipe with the skip test in their shadow, hits corrected (lo.hi + hi.lo) in the batched flush; lane-local top-M)" % ((d_t + 15) // 16, 6 if k <= 5 else 8),
             "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": frac, "traffic": traffic, "traffic_note": traffic_note,
-            "executed_over_algorithmic_mfma": 1.0,
+            "traffic_all_kernels_of_the_step": traffic_step,
+            "traffic_over_algorithmic_bytes_step": (traffic_step / alg_bytes) if traffic_step else None,
+            "algorithmic_bytes_step": alg_bytes,
+            "executed_over_algorithmic_mfma": st.get("mfma_executed_ratio"),
             "vs_f32_mfma_peak": achieved_tf / PEAK_F32_MFMA_TFLOPS,
             "kernel_ms_per_step": coarse_ms, "kernel_rows_per_step": rows_timed, "all_kernels_ms_per_step": kernel_ms,
             "timed_calls": int(st["timed_calls"]),
@@ -394,6 +430,7 @@ def main():
                 "parallelism": f"query-row shards x{world}",
             },
             "roofline": roofline,
+            "library_sha16": library_sha16(),
             "fit_seconds": t_fit,
             "exact_fallbacks_per_step": int(st["exact_fallbacks"] / args.steps), "queries_answered": int(st["queries"]),
         }

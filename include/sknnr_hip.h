@@ -116,6 +116,10 @@ typedef struct sknnr_stats {
     int64_t coarse_rows_timed; /* query rows processed by the pre-filter launches that total_coarse_ms sums: all rows of a
                                   call, except that when the thin last round runs beside the finaliser (side stream)
                                   only the 16-wave bulk launch is timed -- the rows to price its time against */
+    double  mfma_executed_ratio; /* matrix work the most recent pre-filter launch ISSUED over the algorithmic
+                                  2 nq n_ref d: reference rows padded to whole tiles / stages, the seed window swept
+                                  twice, K padded to 16 (second-generation kernel: exact; first generation: its main
+                                  products only, the correction products of visited tiles come on top) */
 } sknnr_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

@@ -87,6 +87,7 @@ class Stats(ctypes.Structure):
         ("total_coarse_ms", c_double),
         ("timed_calls", c_int64),
         ("coarse_rows_timed", c_int64),
+        ("mfma_executed_ratio", c_double),
     ]
 
     def as_dict(self) -> dict:

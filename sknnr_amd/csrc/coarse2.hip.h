@@ -53,6 +53,13 @@ __host__ __device__ constexpr int tiles_per_stage2(int ks) { return ks <= 2 ? SK
 #define SKNNR_SEED_TILES 64
 #endif
 constexpr int kSeedTiles = SKNNR_SEED_TILES;
+// Tiles of the seed window for an image of n_tiles tiles: at most kSeedTiles and at most an eighth of the image (a
+// 10,000-row set has 320 tiles: 64 swept twice would be a fifth of its sweep), whole stages, at least one.
+__host__ __device__ constexpr int seed_tiles_for(long n_tiles, int tps) {
+    const long want = n_tiles / 8 < kSeedTiles ? n_tiles / 8 : kSeedTiles;
+    const long stages = want / tps < 1 ? 1 : want / tps;
+    return (int)(stages * tps);
+}
 constexpr int kCoarse2Waves = SKNNR_V2_WAVES;
 constexpr int kCoarse2Nqb = 2;
 constexpr int kQueueCap = 5;      // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
@@ -61,7 +68,12 @@ constexpr int kQueueFlushAt = 3;  // a visit ends with a flush once some lane ho
 __host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb * kQueueCap * 64 * 8 + kCoarse2Nqb * 64 * 4; }
 // measured against coarse_kernel on 4.19M x 50k rows (profiles/r02_v2_vs_v1.txt): 6-entry lists win for KS <= 4, 8-entry
 // lists for KS <= 3 (KS = 4 with 8-entry lists spills 88 bytes and loses)
-__host__ __device__ constexpr bool coarse2_supported(int ks, int m) { return (m == 6 && ks <= 4) || (m == 8 && ks <= 3); }
+#ifndef SKNNR_V2_M2
+#define SKNNR_V2_M2 1  // one neighbour (lists of 2) on the second-generation kernel, up to 32 features
+#endif
+__host__ __device__ constexpr bool coarse2_supported(int ks, int m) {
+    return (m == 6 && ks <= 4) || (m == 8 && ks <= 3) || (SKNNR_V2_M2 && m == 2 && ks <= 2);
+}
 
 // sum_j x[j] * y[j] over one 8-element fragment, f32 accumulate (v_dot2c_f32_f16)
 __device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc) {
@@ -411,7 +423,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #else
     if (n_tiles >= 2 * kSeedTiles) {
 #endif
-        constexpr int SEED_STAGES = kSeedTiles / TPS;
+        const int SEED_STAGES = seed_tiles_for(n_tiles, TPS) / TPS;
         stage_copy(rhi + (size_t)stage_of(0) * STAGE, smem, STAGE, wave, lane, WAVES);
         __syncthreads();
         for (int st = 0; st < SEED_STAGES; ++st) {

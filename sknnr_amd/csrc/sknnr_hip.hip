@@ -7,6 +7,7 @@
 #include "../../include/sknnr_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -14,8 +15,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <future>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -168,6 +174,52 @@ constexpr double eps_units2(int ks) { return 12.0 + 2.0 * ks; }
 // the handle
 // ----------------------------------------------------------------------------------------
 constexpr int kHostSlots = 4;  // tiles in flight in the host-buffer pipeline
+
+// One background host thread that runs posted jobs in order (the host-buffer pipeline's copy-in and copy-out legs:
+// the staging memcpys used to sit in the enqueueing thread, in series with it -- profiles/r02_host_path_probe.txt).
+class HostWorker {
+public:
+    HostWorker() : th_([this] { run(); }) {}
+    ~HostWorker() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    std::future<int> post(std::function<int()> fn) {
+        std::packaged_task<int()> task(std::move(fn));
+        std::future<int> f = task.get_future();
+        {
+            std::lock_guard<std::mutex> l(m_);
+            q_.emplace_back(std::move(task));
+        }
+        cv_.notify_one();
+        return f;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::packaged_task<int()> task;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;  // stop requested and nothing left to do
+                task = std::move(q_.front());
+                q_.pop_front();
+            }
+            task();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::packaged_task<int()>> q_;
+    bool stop_ = false;
+    std::thread th_;  // (last member: the thread starts when everything above exists)
+};
+
 struct sknnr_index {
     int device = 0;
     long n_ref = 0;
@@ -224,6 +276,7 @@ struct sknnr_index {
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
     } slot[kHostSlots];
     hipStream_t st_h2d = nullptr, st_run = nullptr, st_d2h = nullptr;
+    std::unique_ptr<HostWorker> w_in, w_out;  // copy-in (look-ahead) and copy-out legs of the host pipeline
 
     // Workspace hand-over between calls on different streams: the last launch of a call records
     // ev_ws; the next call's stream waits for it before it touches the workspace.
@@ -253,6 +306,8 @@ struct sknnr_index {
     sknnr_stats stats{};
 
     ~sknnr_index() {
+        w_in.reset();   // (joins: no job may outlive the buffers below)
+        w_out.reset();
         (void)hipSetDevice(device);
         for (auto* b : {&center, &scale, &proj, &ref64, &refT, &rn64, &y64, &mu_dev, &xt, &qnc, &xstage,
                         &dist_stage, &pred_stage})
@@ -382,29 +437,32 @@ static bool mahalanobis_norms(const double* ref, int64_t n_ref, int d, const std
     return true;
 }
 
-// returns 0: the caller's order, 1: increasing centred norm, 2: a fixed pseudo-random shuffle (for callers
-// whose rows are sorted by something that correlates with the features: the first tiles would then
-// cover one corner of the cloud only)
-// (... 3: increasing Mahalanobis norm, when `mnorm` is available)
-static int choose_image_order(const double* ref, int64_t n_ref, int d, const std::vector<double>& cnorm,
-                              const std::vector<double>* mnorm) {
-    if (std::getenv("SKNNR_IMAGE_ORDER")) return std::atoi(std::getenv("SKNNR_IMAGE_ORDER"));
-    if (n_ref < 2048) return 0;
-    const int S = (int)std::min<int64_t>(n_ref, 8192), NQ = 64, J = 6;
-    const int64_t stride = n_ref / S;
-    std::vector<int> sample(S);
-    for (int i = 0; i < S; ++i) sample[i] = (int)(i * stride);
-    std::vector<int> by_norm(sample);
-    std::stable_sort(by_norm.begin(), by_norm.end(), [&](int a, int b) { return cnorm[(size_t)a] < cnorm[(size_t)b]; });
-    // pseudo-queries
-    std::vector<double> q((size_t)NQ * d);
+// Replay of the pre-filter's visit rule on a sample, shared by the choices below: 64 pseudo-queries (a sampled row
+// displaced by 0.35 x the difference of two others) sweep up to 8192 sampled rows in tiles of 32, keeping the 6 best
+// per query; counted are the (tile, 32-query block) pairs in which some query of the block has a value below its
+// threshold as of the start of the tile.
+struct OrderSim {
+    const double* ref;
+    int64_t n_ref;
+    int d, S, NQ = 64, J = 6;
+    int64_t stride;
+    std::vector<int> sample;
+    std::vector<double> q;
     uint64_t rng = 0x9E3779B97F4A7C15ull;
-    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (int64_t)(rng % (uint64_t)n_ref); };
-    for (int i = 0; i < NQ; ++i) {
-        const int64_t a = next(), b = next(), c = next();
-        for (int k = 0; k < d; ++k) q[(size_t)i * d + k] = ref[a * d + k] + 0.35 * (ref[b * d + k] - ref[c * d + k]);
+    OrderSim(const double* ref_, int64_t n_ref_, int d_) : ref(ref_), n_ref(n_ref_), d(d_) {
+        S = (int)std::min<int64_t>(n_ref, 8192);
+        stride = n_ref / S;
+        sample.resize(S);
+        for (int i = 0; i < S; ++i) sample[i] = (int)(i * stride);
+        q.resize((size_t)NQ * d);
+        auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (int64_t)(rng % (uint64_t)n_ref); };
+        for (int i = 0; i < NQ; ++i) {
+            const int64_t a = next(), b = next(), c = next();
+            for (int k = 0; k < d; ++k) q[(size_t)i * d + k] = ref[a * d + k] + 0.35 * (ref[b * d + k] - ref[c * d + k]);
+        }
     }
-    auto visits = [&](const std::vector<int>& order) {
+    // `order`: S row ids; `start` (optional): per query, the position of `order` at which its sweep begins (rotation)
+    long visits(const std::vector<int>& order, const std::vector<int>* start = nullptr) const {
         std::vector<double> best((size_t)NQ * J, std::numeric_limits<double>::infinity());
         long n_vis = 0;
         for (int t0 = 0; t0 + 32 <= S; t0 += 32) {
@@ -413,8 +471,9 @@ static int choose_image_order(const double* ref, int64_t n_ref, int d, const std
                 for (int qi = qb * 32; qi < qb * 32 + 32; ++qi) {
                     double* bq = &best[(size_t)qi * J];
                     const double thr = bq[J - 1];  // threshold as of the start of the tile, like the kernel's
+                    const int base = start ? (*start)[(size_t)qi] : 0;
                     for (int r = t0; r < t0 + 32; ++r) {
-                        const double* rr = ref + (int64_t)order[r] * d;
+                        const double* rr = ref + (int64_t)order[(size_t)((base + r) % S)] * d;
                         double d2 = 0.0;
                         for (int k = 0; k < d; ++k) {
                             const double t = q[(size_t)qi * d + k] - rr[k];
@@ -434,10 +493,24 @@ static int choose_image_order(const double* ref, int64_t n_ref, int d, const std
             }
         }
         return n_vis;
-    };
+    }
+};
+
+// returns 0: the caller's order, 1: increasing centred norm, 2: a fixed pseudo-random shuffle (for callers
+// whose rows are sorted by something that correlates with the features: the first tiles would then
+// cover one corner of the cloud only)
+// (... 3: increasing Mahalanobis norm, when `mnorm` is available); *best_visits: the winner's visit count
+static int choose_image_order(OrderSim& sim, const std::vector<double>& cnorm, const std::vector<double>* mnorm, long* best_visits) {
+    *best_visits = -1;
+    if (std::getenv("SKNNR_IMAGE_ORDER")) return std::atoi(std::getenv("SKNNR_IMAGE_ORDER"));
+    if (sim.n_ref < 2048) return 0;
+    const int S = sim.S;
+    std::vector<int> by_norm(sim.sample);
+    std::stable_sort(by_norm.begin(), by_norm.end(), [&](int a, int b) { return cnorm[(size_t)a] < cnorm[(size_t)b]; });
     // the sample in a fixed pseudo-random order (a strided walk is already spread over the rows; the
     // shuffle removes what is left of the caller's ordering)
-    std::vector<int> shuffled(sample);
+    std::vector<int> shuffled(sim.sample);
+    uint64_t rng = sim.rng;
     for (int i = S - 1; i > 0; --i) {
         rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
         std::swap(shuffled[i], shuffled[(int)(rng % (uint64_t)(i + 1))]);
@@ -445,20 +518,20 @@ static int choose_image_order(const double* ref, int64_t n_ref, int d, const std
     // caller's order on CONSECUTIVE rows (what the image would really hold tile by tile)
     std::vector<int> head(S);
     for (int i = 0; i < S; ++i) head[i] = i;
-    const long v_orig = std::max(visits(sample), visits(head)), v_norm = visits(by_norm), v_shuf = visits(shuffled);
+    const long v_orig = std::max(sim.visits(sim.sample), sim.visits(head)), v_norm = sim.visits(by_norm), v_shuf = sim.visits(shuffled);
     long best = v_orig;
     int choice = 0;
     if (v_shuf * 100 < best * 93) { best = v_shuf; choice = 2; }
     if (v_norm * 100 < best * 93) { best = v_norm; choice = 1; }
     if (mnorm) {
-        std::vector<int> by_mah(sample);
+        std::vector<int> by_mah(sim.sample);
         std::stable_sort(by_mah.begin(), by_mah.end(), [&](int a, int b) { return (*mnorm)[(size_t)a] < (*mnorm)[(size_t)b]; });
-        const long v_mah = visits(by_mah);
+        const long v_mah = sim.visits(by_mah);
         if (v_mah * 100 < best * (choice == 0 ? 93 : 97)) { best = v_mah; choice = 3; }
     }
+    *best_visits = best;
     return choice;
 }
-
 
 // ----------------------------------------------------------------------------------------
 // cell order of the second-generation image (bucket.hip.h)
@@ -679,7 +752,9 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         std::vector<double> mnorm;
         const char* forced = std::getenv("SKNNR_IMAGE_ORDER");
         const bool have_mah = (!forced || std::atoi(forced) == 3) && n_ref >= 2048 && mahalanobis_norms(ref, n_ref, d, ix->mu, mnorm);
-        int image_order = choose_image_order(ref, n_ref, d, cnorm, have_mah ? &mnorm : nullptr);
+        OrderSim sim(ref, n_ref, d);
+        long order_visits = -1;
+        int image_order = choose_image_order(sim, cnorm, have_mah ? &mnorm : nullptr, &order_visits);
         if (image_order == 3 && !have_mah) image_order = 1;
         if (image_order == 1) {
             std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return cnorm[(size_t)a] < cnorm[(size_t)b]; });
@@ -747,12 +822,50 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
                 while (want > 0 && (n_ref >> want) < 512) --want;  // cells of at least 512 rows (one 16-tile stage)
                 if (n_tiles2 >= 2 * kSeedTiles && want >= 2) depth = want;
             }
+            const bool cells_forced = std::getenv("SKNNR_CELLS") != nullptr;
+            CellTree tree;
+            auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
             if (depth > 0) {
-                const CellTree tree = build_cell_tree(ref, n_ref, d, ix->mu, depth);
+                tree = build_cell_tree(ref, n_ref, d, ix->mu, depth);
+                if (!cells_forced && order_visits > 0) {
+                    // Does the cell order pay for THIS reference set?  The same replay as for the other orders, every
+                    // pseudo-query starting its sweep around its own cell.  Isotropic clouds (whitened Mahalanobis
+                    // spaces, uniform hypercubes) have no leading axes to split along: they keep the order chosen above
+                    // (measured, 10M x 50k x 64 Mahalanobis: 68 ms by norm, 91 ms by cells).
+                    std::vector<int> by_cell(sim.sample);
+                    std::stable_sort(by_cell.begin(), by_cell.end(), [&](int a, int b) {
+                        if (tree.code[(size_t)a] != tree.code[(size_t)b]) return tree.code[(size_t)a] < tree.code[(size_t)b];
+                        return mix((uint32_t)a) < mix((uint32_t)b);
+                    });
+                    const int n_cells = 1 << depth;
+                    std::vector<int> first_s((size_t)n_cells + 1, sim.S);
+                    for (int pos = sim.S - 1; pos >= 0; --pos) first_s[(size_t)tree.code[(size_t)by_cell[(size_t)pos]]] = pos;
+                    for (int c = n_cells - 1; c >= 0; --c)
+                        if (first_s[(size_t)c] == sim.S) first_s[(size_t)c] = first_s[(size_t)c + 1];
+                    const int window = std::max<int>(32, (int)((int64_t)seed_tiles_for(n_tiles2, tps2) * 32 * sim.S / n_ref));
+                    std::vector<int> start((size_t)sim.NQ);
+                    for (int qi = 0; qi < sim.NQ; ++qi) {
+                        int node = 0;
+                        for (int l = 0; l < depth; ++l) {
+                            float z = 0.f;
+                            for (int k = 0; k < d; ++k)
+                                z = std::fmaf((float)sim.q[(size_t)qi * d + k] - tree.centre[(size_t)k], tree.axes[(size_t)l * d + k], z);
+                            node = 2 * node + (z >= tree.thr[((size_t)1 << l) - 1 + node] ? 1 : 0);
+                        }
+                        const int mid = (first_s[(size_t)node] + first_s[(size_t)node + 1]) / 2;
+                        start[(size_t)qi] = ((mid - window / 2) % sim.S + sim.S) % sim.S;
+                    }
+                    const long v_cell = sim.visits(by_cell, &start);
+                    if (v_cell * 100 >= order_visits * 85) depth = 0;
+                    if (std::getenv("SKNNR_ORDER_TRACE"))
+                        std::fprintf(stderr, "[order] best plain order %d: %ld visits; cell order (depth %d): %ld visits -> %s\n", image_order,
+                                     order_visits, tree.depth, v_cell, depth ? "cells" : "plain");
+                }
+            }
+            if (depth > 0) {
                 for (int64_t i = 0; i < n_ref; ++i) perm2[(size_t)i] = (int)i;
                 // (inside a cell: a fixed pseudo-random order -- sorted by norm, a query's nearest rows would share a few
                 //  tiles and overflow the per-lane hit queues there)
-                auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
                 const bool by_norm = std::getenv("SKNNR_CELL_NORM_ORDER") != nullptr;
                 std::stable_sort(perm2.begin(), perm2.end(), [&](int a, int b) {
                     if (tree.code[(size_t)a] != tree.code[(size_t)b]) return tree.code[(size_t)a] < tree.code[(size_t)b];
@@ -768,8 +881,9 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
                 for (int c = 0; c < n_cells; ++c) {
                     // the seed window (kSeedTiles tiles) is centred on the cell
                     const long mid_tile = (first[(size_t)c] + first[(size_t)c + 1]) / 2 / 32;
-                    long st = (mid_tile - kSeedTiles / 2) / tps2;
-                    if (mid_tile - kSeedTiles / 2 < 0) st = ix->n_stages2 + (mid_tile - kSeedTiles / 2 - tps2 + 1) / tps2;
+                    const long half = seed_tiles_for(n_tiles2, tps2) / 2;
+                    long st = (mid_tile - half) / tps2;
+                    if (mid_tile - half < 0) st = ix->n_stages2 + (mid_tile - half - tps2 + 1) / tps2;
                     stage[(size_t)c] = (int)(((st % ix->n_stages2) + ix->n_stages2) % ix->n_stages2);
                 }
                 HIP_TRY(ix->cell_axes.ensure(tree.axes.size()));
@@ -1200,6 +1314,8 @@ bool use_coarse2(const sknnr_index* ix, int m_list) {
 }
 
 int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
+    if (ix->ks == 1 && m_list == 2) return launch_coarse2_ks<1, 2>(ix, nq_pad, kk, st);
+    if (ix->ks == 2 && m_list == 2) return launch_coarse2_ks<2, 2>(ix, nq_pad, kk, st);
     if (ix->ks == 1 && m_list == 6) return launch_coarse2_ks<1, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 1 && m_list == 8) return launch_coarse2_ks<1, 8>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 6) return launch_coarse2_ks<2, 6>(ix, nq_pad, kk, st);
@@ -1505,6 +1621,13 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         }
         ix->bulk_rows_done = 0;
         ix->ev_bulk_end = ev.second;
+        {
+            // matrix work issued / algorithmic (rows of the launch cancel): K-steps x tiles swept over d x n_ref
+            const long tiles = v2 ? (long)ix->n_stages2 * tiles_per_stage2(ix->ks) +
+                                        seed_tiles_for((long)ix->n_stages2 * tiles_per_stage2(ix->ks), tiles_per_stage2(ix->ks))
+                                  : (long)ix->n_stages * tiles_per_stage(ix->ks);
+            ix->stats.mfma_executed_ratio = (double)tiles * 32.0 * (16.0 * ix->ks) / ((double)ix->n_ref * ix->d);
+        }
         int rc = v2 ? launch_coarse2(ix, n_pad, coarse_list_len(kk), kk, st)
                     : launch_coarse(ix, n_pad, coarse_list_len(kk), kk, st);
         if (rc) return rc;
@@ -1663,8 +1786,15 @@ struct HostPipe {
         double* od = nullptr;
         long* oi = nullptr;
         double* op = nullptr;
+        std::future<int> out_done;  // copy-out job of the slot's tile (w_out)
     } pending[kHostSlots];
     int slot_of = 0;
+    // look-ahead copy-in (one-shot calls know their next tile): the job that stages tile `ahead_tile` into slot `ahead_slot`
+    std::packaged_task<int()> deferred[kHostSlots];  // SKNNR_PIPE_WORKERS=0: the copy-out jobs, run when the slot is drained
+    std::future<int> ahead_done;
+    const double* ahead_q = nullptr;
+    int ahead_slot = -1;
+    int d2h_slot = -1;  // slot whose kernels are enqueued and whose device-to-host copies are not yet (pipe_enqueue_d2h)
     double ms_copy_in = 0, ms_copy_out = 0, ms_wait = 0, ms_enqueue = 0;  // host-thread time per phase (SKNNR_PIPE_TRACE=1)
 };
 
@@ -1692,31 +1822,35 @@ int pipe_open(HostPipe& p, sknnr_index* ix, const sknnr_query_opts* o, bool want
     for (auto& sl : ix->slot)
         for (hipEvent_t* e : {&sl.ev_h2d, &sl.ev_done, &sl.ev_d2h})
             if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (!ix->w_in) ix->w_in.reset(new HostWorker());
+    if (!ix->w_out) ix->w_out.reset(new HostWorker());
     return SKNNR_OK;
 }
 
-// copy slot b's finished results to the caller's arrays
+// Slot b's previous tile has left (its copy-out job, on w_out, is done): the slot's buffers may be reused.
+int pipe_enqueue_d2h(HostPipe& p);
 int pipe_drain(HostPipe& p, int b) {
     auto& pd = p.pending[b];
     if (!pd.live) return SKNNR_OK;
-    auto& sl = p.ix->slot[b];
+    if (p.d2h_slot == b) {  // (its results have not even been sent yet)
+        int rc = pipe_enqueue_d2h(p);
+        if (rc) return rc;
+    }
     const double t0 = now_ms();
-    HIP_TRY(hipEventSynchronize(sl.ev_d2h));
-    const double t1 = now_ms();
-    if (pd.oi) parallel_copy(pd.oi, sl.pin_i, (size_t)pd.n * p.k * sizeof(long));
-    if (pd.od) parallel_copy(pd.od, sl.pin_d, (size_t)pd.n * p.k * sizeof(double));
-    if (pd.op) parallel_copy(pd.op, sl.pin_p, (size_t)pd.n * p.t * sizeof(double));
-    p.ms_wait += t1 - t0;
-    p.ms_copy_out += now_ms() - t1;
+    if (p.deferred[b].valid()) {
+        p.deferred[b]();
+        p.deferred[b] = std::packaged_task<int()>();
+    }
+    const int rc = pd.out_done.valid() ? pd.out_done.get() : SKNNR_OK;
+    p.ms_wait += now_ms() - t0;
     pd.live = false;
+    if (rc) return fail(rc, "host pipeline: copying a tile's results out failed (HIP error while waiting for the device-to-host copy)");
     return SKNNR_OK;
 }
 
-// One tile of at most host_chunk_rows() rows.  `q` may be reused by the caller as soon as this returns.
-int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, double* op) {
+// Drain slot b and size its pinned / device buffers for a tile of n rows.
+int pipe_prepare_slot(HostPipe& p, int b, long n) {
     sknnr_index* ix = p.ix;
-    const int b = p.slot_of;
-    p.slot_of = (p.slot_of + 1) % kHostSlots;
     auto& sl = ix->slot[b];
     int rc = pipe_drain(p, b);  // the slot's previous tile must have left before its buffers are reused
     if (rc) return rc;
@@ -1729,13 +1863,85 @@ int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, doub
     HIP_TRY(sl.dev_i.ensure((size_t)n * k));
     HIP_TRY(sl.dev_d.ensure((size_t)n * k));
     if (p.want_pred) HIP_TRY(sl.dev_p.ensure((size_t)n * t));
+    return SKNNR_OK;
+}
 
+// Device-to-host copies and the copy-out job of the tile whose kernels were enqueued last (slot p.d2h_slot), if any.
+// BOTH directions use one stream (st_h2d), tile j's rows in front of tile j-1's results: on this stack a device-to-host
+// copy that runs while a host-to-device copy is active is not given a DMA engine but executed by a blit kernel
+// (__amd_rocclr_copyBuffer, six pieces of ~0.5 ms per tile in a rocprofv3 trace) that shares the CUs with the hot path
+// -- the prep kernel beside it took 1.18 ms instead of 0.30, a tile 7.75 ms instead of 5.8 (profiles/r03_host_pipeline.txt).
+// One stream keeps every transfer on the DMA engine; per tile 4.5 ms in + 1.4 ms out still fit beside 5.8 ms of kernels.
+int pipe_enqueue_d2h(HostPipe& p) {
+    const int b = p.d2h_slot;
+    if (b < 0) return SKNNR_OK;
+    p.d2h_slot = -1;
+    sknnr_index* ix = p.ix;
+    auto& sl = ix->slot[b];
+    auto& pd = p.pending[b];
+    const long n = pd.n;
+    const int k = p.k, t = p.t;
+    double* od = pd.od;
+    long* oi = pd.oi;
+    double* op = pd.op;
+    static const bool one_stream = [] { const char* e = std::getenv("SKNNR_PIPE_ONE_STREAM"); return !(e && std::atoi(e) == 0); }();
+    hipStream_t st = one_stream ? ix->st_h2d : ix->st_d2h;
+    HIP_TRY(hipStreamWaitEvent(st, sl.ev_done, 0));
+    if (oi) HIP_TRY(hipMemcpyAsync(sl.pin_i, sl.dev_i.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, st));
+    if (od) HIP_TRY(hipMemcpyAsync(sl.pin_d, sl.dev_d.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (op) HIP_TRY(hipMemcpyAsync(sl.pin_p, sl.dev_p.p, (size_t)n * t * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(sl.ev_d2h, st));
+    // the copy-out leg: wait for the tile's device-to-host copies, then pinned -> the caller's arrays (w_out, in order)
+    static const bool workers = [] { const char* e = std::getenv("SKNNR_PIPE_WORKERS"); return !(e && std::atoi(e) == 0); }();
+    {
+        const int device = ix->device;
+        hipEvent_t ev = sl.ev_d2h;
+        const long* pin_i = sl.pin_i;
+        const double *pin_d = sl.pin_d, *pin_p = sl.pin_p;
+        auto job = [=]() -> int {
+            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev) != hipSuccess) return SKNNR_ERR_HIP;
+            if (oi) parallel_copy(oi, pin_i, (size_t)n * k * sizeof(long));
+            if (od) parallel_copy(od, pin_d, (size_t)n * k * sizeof(double));
+            if (op) parallel_copy(op, pin_p, (size_t)n * t * sizeof(double));
+            return SKNNR_OK;
+        };
+        if (workers) {
+            pd.out_done = ix->w_out->post(job);
+        } else {  // (A/B: the round-2 behaviour -- the copy runs on this thread when the slot is drained)
+            std::packaged_task<int()> task(job);
+            pd.out_done = task.get_future();
+            p.deferred[b] = std::move(task);
+        }
+    }
+    return SKNNR_OK;
+}
+
+// One tile of at most host_chunk_rows() rows.  `q` may be reused by the caller as soon as this returns.
+// q_next / n_next: the tile the same call will submit next (or null): its rows are staged into the next slot's pinned
+// buffer by the copy-in worker while this tile is enqueued and the caller waits for older results.
+int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, double* op, const double* q_next = nullptr,
+                long n_next = 0) {
+    sknnr_index* ix = p.ix;
+    const int b = p.slot_of;
+    p.slot_of = (p.slot_of + 1) % kHostSlots;
+    auto& sl = ix->slot[b];
+    const int k = p.k, d_x = p.d_x;
+    int rc;
     const double t_in = now_ms();
-    parallel_copy(sl.pin_x, q, (size_t)n * d_x * sizeof(double));
+    if (p.ahead_slot == b && p.ahead_q == q && p.ahead_done.valid()) {
+        rc = p.ahead_done.get();  // staged ahead by the worker (the slot was prepared when the job was posted)
+        p.ahead_slot = -1;
+        if (rc) return rc;
+    } else {
+        if ((rc = pipe_prepare_slot(p, b, n))) return rc;
+        parallel_copy(sl.pin_x, q, (size_t)n * d_x * sizeof(double));
+    }
     const double t_enq = now_ms();
     p.ms_copy_in += t_enq - t_in;
     HIP_TRY(hipMemcpyAsync(sl.dev_x.p, sl.pin_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, ix->st_h2d));
     HIP_TRY(hipEventRecord(sl.ev_h2d, ix->st_h2d));
+    // the PREVIOUS tile's results travel behind this tile's rows, on the same stream (see pipe_enqueue_d2h)
+    if ((rc = pipe_enqueue_d2h(p))) return rc;
     HIP_TRY(hipStreamWaitEvent(ix->st_run, sl.ev_h2d, 0));
     rc = run_device(ix, sl.dev_x.p, n, &p.o, sl.dev_d.p, sl.dev_i.p, ix->st_run);
     if (rc) return rc;
@@ -1744,36 +1950,74 @@ int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, doub
         if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(sl.ev_done, ix->st_run));
-    HIP_TRY(hipStreamWaitEvent(ix->st_d2h, sl.ev_done, 0));
-    if (oi) HIP_TRY(hipMemcpyAsync(sl.pin_i, sl.dev_i.p, (size_t)n * k * sizeof(long), hipMemcpyDeviceToHost, ix->st_d2h));
-    if (od) HIP_TRY(hipMemcpyAsync(sl.pin_d, sl.dev_d.p, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ix->st_d2h));
-    if (op) HIP_TRY(hipMemcpyAsync(sl.pin_p, sl.dev_p.p, (size_t)n * t * sizeof(double), hipMemcpyDeviceToHost, ix->st_d2h));
-    HIP_TRY(hipEventRecord(sl.ev_d2h, ix->st_d2h));
     auto& pd = p.pending[b];
     pd.live = true;
     pd.n = n;
     pd.od = od;
     pd.oi = oi;
     pd.op = op;
+    p.d2h_slot = b;  // its device-to-host copies are enqueued behind the next tile's rows, or by the flush
     p.o.row_offset += n;
     p.ms_enqueue += now_ms() - t_enq;
+    static const bool workers = [] { const char* e = std::getenv("SKNNR_PIPE_WORKERS"); return !(e && std::atoi(e) == 0); }();
+    if (workers && q_next && n_next > 0) {
+        // the copy-in leg of the next tile (w_in): its slot is drained and sized here, on this thread
+        const int b2 = p.slot_of;
+        if ((rc = pipe_prepare_slot(p, b2, n_next))) return rc;
+        double* dst = ix->slot[b2].pin_x;
+        const size_t bytes = (size_t)n_next * d_x * sizeof(double);
+        p.ahead_done = ix->w_in->post([=]() -> int {
+            parallel_copy(dst, q_next, bytes);
+            return SKNNR_OK;
+        });
+        p.ahead_q = q_next;
+        p.ahead_slot = b2;
+    }
     return SKNNR_OK;
 }
 
-// Submit `nq` rows in tiles of at most host_chunk_rows().
+// Submit `nq` rows in tiles of at most host_chunk_rows().  A pipeline that starts empty ramps up: the device waits for
+// the first tile's staging copy and host-to-device transfer (7 ms for a 1M-row tile) with nothing to do, so the first
+// tiles are an eighth, a quarter and a half of the regular size.
 int pipe_submit_rows(HostPipe& p, const double* q, long nq, double* od, long* oi, double* op) {
     const long cap = host_chunk_rows();
-    for (long c0 = 0; c0 < nq; c0 += cap) {
-        const long n = std::min(cap, nq - c0);
+    bool idle = p.d2h_slot < 0;
+    for (const auto& pd : p.pending) idle = idle && !pd.live;
+    std::vector<long> cuts;  // tile boundaries
+    long c = 0;
+    if (idle && nq > cap / 2 && !std::getenv("SKNNR_PIPE_NO_RAMP"))
+        for (long part : {cap / 8, cap / 4, cap / 2}) {
+            part = std::max<long>(part / kRowQuantum * kRowQuantum, kRowQuantum);
+            if (c + part >= nq) break;
+            c += part;
+            cuts.push_back(c);
+        }
+    while (c < nq) {
+        c = std::min(nq, c + cap);
+        cuts.push_back(c);
+    }
+    long c0 = 0;
+    for (size_t i = 0; i < cuts.size(); ++i) {
+        const long c1 = cuts[i], n = c1 - c0;
+        const long n_next = i + 1 < cuts.size() ? cuts[i + 1] - c1 : 0;
         int rc = pipe_submit(p, q + c0 * p.d_x, n, od ? od + c0 * p.k : nullptr, oi ? oi + c0 * p.k : nullptr,
-                             op ? op + c0 * p.t : nullptr);
+                             op ? op + c0 * p.t : nullptr, n_next ? q + c1 * p.d_x : nullptr, n_next);
         if (rc) return rc;
+        c0 = c1;
     }
     return SKNNR_OK;
 }
 
 // Everything submitted so far is in the caller's arrays when this returns; reports non-finite input.
 int pipe_flush(HostPipe& p) {
+    if (p.ahead_done.valid()) {  // (a look-ahead copy nobody consumed: only after a failed submit)
+        (void)p.ahead_done.get();
+        p.ahead_slot = -1;
+    }
+    {
+        int rc = pipe_enqueue_d2h(p);  // the last tile's results have nobody behind them
+        if (rc) return rc;
+    }
     for (int i = 0; i < kHostSlots; ++i) {
         int rc = pipe_drain(p, (p.slot_of + i) % kHostSlots);  // oldest tile first (the next slot to be reused)
         if (rc) return rc;
@@ -1790,15 +2034,62 @@ int pipe_flush(HostPipe& p) {
     return SKNNR_OK;
 }
 
+// After a failed submit: no posted job may still touch the caller's memory or the slots when the call returns.
+void pipe_abort(HostPipe& p) {
+    if (p.ahead_done.valid()) (void)p.ahead_done.get();
+    p.ahead_slot = -1;
+    p.d2h_slot = -1;
+    for (int b = 0; b < kHostSlots; ++b) {
+        auto& pd = p.pending[b];
+        if (p.deferred[b].valid()) {
+            p.deferred[b]();
+            p.deferred[b] = std::packaged_task<int()>();
+        }
+        if (pd.out_done.valid()) (void)pd.out_done.get();
+        pd.live = false;
+    }
+}
+
+// Fresh output arrays (numpy's np.empty) are untouched memory: the first write to every page is a fault, and the
+// copy-out leg would take them one by one in the middle of the pipeline.  MADV_POPULATE_WRITE (Linux >= 5.14) makes the
+// pages present and writable without changing what they hold, so it may run beside the copies; a few threads, because
+// the kernel zero-fills the pages it hands out.  Unsupported kernels answer EINVAL: then the copies fault as before.
+struct Prefault {
+    std::vector<std::thread> th;
+    void add(void* ptr, size_t bytes) {
+        if (!ptr || bytes < (8u << 20)) return;
+        const uintptr_t lo = ((uintptr_t)ptr + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)ptr + bytes) & ~(uintptr_t)4095;
+        if (hi <= lo) return;
+        const unsigned n = 4;
+        const size_t per = (((hi - lo) / n) + 4095) & ~(size_t)4095;
+        for (unsigned i = 0; i < n; ++i) {
+            const uintptr_t a = lo + (uintptr_t)i * per;
+            if (a >= hi) break;
+            const size_t len = std::min<size_t>(per, hi - a);
+            th.emplace_back([a, len] { (void)madvise((void*)a, len, 23 /* MADV_POPULATE_WRITE */); });
+        }
+    }
+    ~Prefault() {
+        for (auto& t : th) t.join();
+    }
+};
+
 int run_host_pipeline(sknnr_index* ix, const double* q, long nq, const sknnr_query_opts* o, double* out_dist,
                       long* out_idx, double* out_pred) {
     if (ix->stream_open) return fail(SKNNR_ERR_INVALID, "a query stream is open on this handle: end it first");
     HostPipe p;
     int rc = pipe_open(p, ix, o, out_dist != nullptr, true, out_pred != nullptr);
+    Prefault pf;  // (joined when the call returns)
+    if (!rc && std::getenv("SKNNR_PREFAULT")) {  // (measured: 96 ms without, 115 ms with -- the populate threads take bandwidth the copies need)
+        pf.add(out_idx, (size_t)nq * o->n_neighbors * sizeof(long));
+        pf.add(out_dist, (size_t)nq * o->n_neighbors * sizeof(double));
+        pf.add(out_pred, (size_t)nq * ix->t * sizeof(double));
+    }
     if (!rc) rc = pipe_submit_rows(p, q, nq, out_dist, out_idx, out_pred);
     if (!rc) rc = pipe_flush(p);
     if (rc) {
         const std::string msg = g_last_error;
+        pipe_abort(p);
         (void)hipDeviceSynchronize();  // nothing of a failed call may still be in flight on the slots
         g_last_error = msg;
     }
@@ -2171,8 +2462,8 @@ extern "C" int sknnr_stream_push(sknnr_stream* s, const double* q, int64_t nq, d
     int rc = pipe_submit_rows(p, q, nq, out_dist, (long*)out_idx, out_pred);
     if (rc) {
         const std::string msg = g_last_error;
+        pipe_abort(p);
         (void)hipDeviceSynchronize();
-        for (auto& pd : p.pending) pd.live = false;
         g_last_error = msg;
         return rc;
     }

@@ -60,7 +60,7 @@ def test_struct_layouts_match_the_header(native):
     assert ctypes.sizeof(native.QueryOpts) == 40
     assert native.QueryOpts.row_offset.offset == 32
     assert native.QueryOpts.check_finite.offset == 28
-    assert ctypes.sizeof(native.Stats) == 80
+    assert ctypes.sizeof(native.Stats) == 88  # ABI v4: + mfma_executed_ratio
     assert native.Stats.total_kernel_ms.offset == 48
 
 
