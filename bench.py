@@ -271,6 +271,50 @@ def extra_config(name, kind, nq, n_ref, d_in, k, torch, device, *, t=40, n_compo
     return res
 
 
+def hamming_config(torch, nq=200_000, n_ref=20_000, n_trees=500, k=5, levels=300, check_rows=1500):
+    """RFNN-shaped workload (REF src/sknnr/_weighted_trees.py:53-59, :139-140): weighted Hamming distance over the node
+    ids of `n_trees` trees, real-valued tree weights, device-resident ids.  Queries are perturbed copies of reference
+    rows (trees agree far more often than random ids do).  Bound: VALU issue -- the integer pre-filter spends three
+    vector instructions per two (pair, tree) compares (hamming.hip.h)."""
+    from oracle import oracle as O
+    from sknnr_amd import _native as N
+
+    rng = np.random.default_rng(0)
+    ref = rng.integers(0, levels, (n_ref, n_trees)).astype(np.float64)
+    src = rng.integers(0, n_ref, nq)
+    q = np.where(rng.random((nq, n_trees)) < 0.6, ref[src], rng.integers(0, levels, (nq, n_trees)).astype(np.float64))
+    w = rng.random(n_trees) + 0.01
+    ix = N.Index(ref)
+    ix.set_hamming_weights(w)
+    o = ix.make_opts(k, formula=N.FORMULA_HAMMING)
+    qd = torch.as_tensor(q, device="cuda")
+    dd = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+    di = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    for _ in range(2):
+        ix.reset_stats()
+        t0 = time.perf_counter()
+        ix.kneighbors_device(qd.data_ptr(), nq, o, dd.data_ptr(), di.data_ptr())
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        st = ix.stats()
+    n_chk = min(check_rows, nq)
+    od, oi = O.kneighbors_hamming(ref, q[:n_chk], w, k)
+    compares = float(n_ref) * nq * n_trees
+    # 256 CUs x 4 SIMDs x 64 lanes, one wave instruction per 4 clocks at 2.4 GHz, 1.5 instructions per compare
+    valu_peak = 256 * 4 * 64 * 2.4e9 / 4 / 1.5
+    res = {"workload": f"RFNN-shaped weighted Hamming: {nq} queries x {n_ref} refs x {n_trees} trees, k={k} (integer pre-filter + float64 re-score)",
+           "Mq_s": nq / wall / 1e6, "ms": wall * 1e3, "kernel_ms": st["total_kernel_ms"],
+           "compares_per_s": compares / (st["total_kernel_ms"] * 1e-3), "bound": "valu",
+           "valu_peak_compares_per_s": valu_peak, "frac": compares / (st["total_kernel_ms"] * 1e-3) / valu_peak,
+           "algorithmic_bytes": float(nq) * n_trees * 8 + float(n_ref) * n_trees * 8 + nq * k * 16,
+           "oracle_check": {"rows": n_chk, "index_rows_equal": int((di[:n_chk].cpu().numpy() == oi).all(axis=1).sum()),
+                            "dist_bit_equal": bool(np.array_equal(dd[:n_chk].cpu().numpy(), od))}}
+    ix.close()
+    del qd, dd, di
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse_args()
     import torch
@@ -508,6 +552,10 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
     cfgs.append(extra_config("C5 MSNRegressor(n_components=8) 6.25M (one GPU's share of 50M) x 100k x 32->8, k=1, dataframe ids",
                              "msn", 6_250_000, 100_000, 32, 1, torch, device, n_components=8, dataframe_ids=True))
     out["configs"] = cfgs
+    try:
+        out["hamming"] = hamming_config(torch)
+    except Exception as err:  # (this line must not cost the headline)
+        out["hamming"] = {"error": repr(err)}
 
     # ---- C5's CPU baseline: sklearn picks a single-threaded kd_tree for D_t <= 15; report brute too ----
     try:

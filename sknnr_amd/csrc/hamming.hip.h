@@ -1,0 +1,264 @@
+// hamming.hip.h -- integer pre-filter + exact re-score for the weighted-Hamming search of RFNN / GBNN (round 3).
+//
+// The reference reaches scipy's cdist(metric="hamming", w=w) through scikit-learn's brute path
+// (REF src/sknnr/_weighted_trees.py:53-59, :139-140): d(q, r) = sum_t w_t [q_t != r_t] / sum_t w_t on float64 node
+// ids, sums in tree order.  exact_scan_kernel<2> replays that arithmetic pair by pair: one float64 compare and one
+// float64 add per (pair, tree) -- 6.3e12 compares/s in round 2.  Node ids are small integers, so here
+//
+//   1. hamming_pack_kernel      query rows (float64 ids) -> 16-bit ids, two trees per dword, [tree pair][query]
+//   2. hamming_coarse_kernel    D^(q, r) = sum_t w^_t [q_t != r_t] with 16-bit integer weights w^_t = round(w_t S):
+//                               per TWO trees one v_xor_b32 (ids differ?), one v_pk_min_u16 (-> 0/1 per half) and one
+//                               v_dot2_u32_u16 (weighted accumulate): 1.5 VALU lane-ops per compare, exact in integers.
+//                               A lane owns a reference row, a workgroup 16 queries (their ids and the weights are
+//                               scalar operands), the reference ids stream from L2 once per 16 queries.  Every row
+//                               whose D^ is within `band` of the running kk-th smallest D^ of its query becomes a
+//                               candidate (appended in index order).
+//   3. hamming_rescore_kernel   the candidates' distances in the reference's own float64 arithmetic, selection by
+//                               (distance, index) exactly as exact_scan_kernel<2> does it over all rows, post-steps.
+//
+// Exactness: |D^ - S sum_t w_t [.]| <= T / 2 (rounding of the weights), the float64 evaluation of the true sum is
+// off by less than 2^-40 of a weight unit; so D^_a + band < D^_b with band = T + 2 implies d_a < d_b in the reference's
+// arithmetic, and a row that is NOT within band of the kk-th smallest D^ has kk rows strictly closer than itself:
+// the kk nearest by (distance, index) are always among the candidates.  A query with more candidates than the list
+// holds, or with an id that is not a 16-bit integer, goes to exact_scan_kernel<2> (fail list), as uncertified rows do
+// on the Euclidean path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "exact.hip.h"
+
+namespace sknnr {
+
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+
+constexpr int kHamNq = 16;          // queries per workgroup (scalar operands: 16 ids + 1 weight pair per tree pair)
+constexpr int kHamWaves = 4;        // 256 reference rows per step
+constexpr int kHamCand = 192;       // candidate slots per query
+constexpr int kHamMaxKK = 32;
+
+// acc += w.lo [r.lo != q.lo] + w.hi [r.hi != q.hi]  for one dword of two packed 16-bit ids: xor, min(x, 1) per half,
+// weighted accumulate.  As raw instructions: hipcc expands a vector min into two compares, two selects and a byte
+// permute, and pads every hand-written instruction it cannot see into with an s_nop.  The query ids and the weights are
+// workgroup-uniform: scalar registers (one constant-bus operand per instruction).
+// (four queries per statement: the compiler pads every asm statement with an s_nop)
+__device__ __forceinline__ void ham_step4(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, uint32_t r, uint32_t q0, uint32_t q1,
+                                          uint32_t q2, uint32_t q3, uint32_t w, uint32_t ones) {
+    uint32_t t0, t1, t2, t3;
+    asm("v_xor_b32 %[t0], %[q0], %[r]\n\t"
+        "v_xor_b32 %[t1], %[q1], %[r]\n\t"
+        "v_xor_b32 %[t2], %[q2], %[r]\n\t"
+        "v_xor_b32 %[t3], %[q3], %[r]\n\t"
+        "v_pk_min_u16 %[t0], %[t0], %[ones]\n\t"
+        "v_pk_min_u16 %[t1], %[t1], %[ones]\n\t"
+        "v_pk_min_u16 %[t2], %[t2], %[ones]\n\t"
+        "v_pk_min_u16 %[t3], %[t3], %[ones]\n\t"
+        "v_dot2_u32_u16 %[a0], %[t0], %[w], %[a0]\n\t"
+        "v_dot2_u32_u16 %[a1], %[t1], %[w], %[a1]\n\t"
+        "v_dot2_u32_u16 %[a2], %[t2], %[w], %[a2]\n\t"
+        "v_dot2_u32_u16 %[a3], %[t3], %[w], %[a3]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [r] "v"(r), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3), [w] "v"(w), [ones] "v"(ones));
+}
+__device__ __forceinline__ void ham_step(unsigned& acc, uint32_t r, uint32_t q, uint32_t w, uint32_t ones) {
+    uint32_t t;
+    asm("v_xor_b32 %[t], %[q], %[r]\n\t"
+        "v_pk_min_u16 %[t], %[t], %[ones]\n\t"
+        "v_dot2_u32_u16 %[acc], %[t], %[w], %[acc]"
+        : [acc] "+v"(acc), [t] "=&v"(t)
+        : [r] "v"(r), [q] "v"(q), [w] "v"(w), [ones] "v"(ones));
+}
+
+struct HammingArgs {
+    const uint32_t* rimg;   // [tp][n_ref_pad] two 16-bit ids per dword
+    const uint32_t* wq;     // [tp] two 16-bit weights per dword
+    const uint32_t* qimg;   // [tp][nq_pad] packed query ids
+    const int* q_bad;       // (nq_pad) 1: the row's ids are not 16-bit integers
+    int n_ref, n_ref_pad, tp;
+    long nq, nq_pad;
+    int kk;
+    unsigned band;
+    int* cand_cnt;          // (nq) out: candidates, or -1 = overflow / bad ids
+    int* cand_id;           // (nq, kHamCand) out, ascending
+};
+
+// float64 ids -> packed 16-bit ids [tp][nq_pad]; rows with an id that is not an integer in [0, 65535] are flagged.
+__global__ void __launch_bounds__(256) hamming_pack_kernel(const double* __restrict__ xq, long nq, long nq_pad, int t, int tp,
+                                                           uint32_t* __restrict__ qimg, int* __restrict__ q_bad) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq_pad) return;
+    bool bad = false;
+    for (int p = 0; p < tp; ++p) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * p + h;
+            double v = (q < nq && c < t) ? xq[q * t + c] : 0.0;
+            const bool ok = v >= 0.0 && v <= 65535.0 && v == floor(v);
+            bad |= !ok;
+            packed |= (ok ? (uint32_t)v : 0u) << (16 * h);
+        }
+        qimg[(size_t)p * nq_pad + q] = packed;
+    }
+    q_bad[q] = (q < nq && bad) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingArgs a) {
+    __shared__ unsigned dbuf[kHamNq][kHamWaves * 64];        // D^ of the step's 256 rows for the 16 queries
+    __shared__ unsigned top[kHamNq][kHamMaxKK];              // the kk smallest D^ so far, ascending
+    __shared__ int cnt[kHamNq];
+    __shared__ int cand[kHamNq][kHamCand];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long q0 = (long)blockIdx.x * kHamNq;
+    for (int i = tid; i < kHamNq * kHamMaxKK; i += kHamWaves * 64) top[i / kHamMaxKK][i % kHamMaxKK] = 0xffffffffu;
+    if (tid < kHamNq) cnt[tid] = 0;
+    __syncthreads();
+    const int KK = a.kk;
+    const uint32_t* qbase = a.qimg + q0;  // + p * nq_pad: 16 consecutive dwords, workgroup-uniform
+    uint32_t ones = 0x00010001u;
+    asm volatile("" : "+v"(ones));  // (a vector register, loaded once)
+
+    for (int j0 = 0; j0 < a.n_ref; j0 += kHamWaves * 64) {
+        const int r = j0 + tid;
+        const uint32_t* rcol = a.rimg + (r < a.n_ref_pad ? r : 0);
+        unsigned acc[kHamNq];
+#pragma unroll
+        for (int j = 0; j < kHamNq; ++j) acc[j] = 0;
+        int p = 0;
+        for (; p + 4 <= a.tp; p += 4) {
+            // four tree pairs per trip: the reference dwords, the weights and the sixteen queries' ids (workgroup-uniform
+            // 64-byte rows) of all four are requested together, then 192 instructions of arithmetic
+            uint32_t rv[4], wv[4];
+            uint4 qv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rv[u] = rcol[(size_t)(p + u) * a.n_ref_pad];
+                wv[u] = a.wq[p + u];
+                const uint4* qp = (const uint4*)(qbase + (size_t)(p + u) * a.nq_pad);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) qv[u][g] = qp[g];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    ham_step4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], rv[u], qv[u][g].x, qv[u][g].y, qv[u][g].z,
+                              qv[u][g].w, wv[u], ones);
+            }
+        }
+        for (; p < a.tp; ++p) {
+            const uint32_t rvv = rcol[(size_t)p * a.n_ref_pad];
+            const uint32_t w = a.wq[p];
+            const uint32_t* qp = qbase + (size_t)p * a.nq_pad;
+#pragma unroll
+            for (int j = 0; j < kHamNq; ++j) ham_step(acc[j], rvv, qp[j], w, ones);
+        }
+        __syncthreads();  // the previous step's selection is done with dbuf
+#pragma unroll
+        for (int j = 0; j < kHamNq; ++j) dbuf[j][tid] = r < a.n_ref ? acc[j] : 0xffffffffu;
+        __syncthreads();
+        // selection: wave w takes queries 4w .. 4w+3; rows in ascending index order
+#pragma unroll 1
+        for (int jj = 0; jj < kHamNq / kHamWaves; ++jj) {
+            const int j = wave * (kHamNq / kHamWaves) + jj;
+            if (q0 + j >= a.nq) break;
+            unsigned kth = top[j][KK - 1];
+#pragma unroll 1
+            for (int u = 0; u < kHamWaves; ++u) {
+                const unsigned v = dbuf[j][64 * u + lane];
+                const unsigned lim = kth > 0xffffffffu - a.band ? 0xffffffffu : kth + a.band;
+                unsigned long long m = __builtin_amdgcn_ballot_w64(v <= lim && v != 0xffffffffu);
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const unsigned vv = __shfl(v, bit, 64);
+                    const unsigned lim2 = kth > 0xffffffffu - a.band ? 0xffffffffu : kth + a.band;
+                    if (vv > lim2) continue;  // the bound has dropped since the ballot
+                    if (lane == 0) {
+                        const int c = cnt[j];
+                        if (c >= 0) {
+                            if (c < kHamCand) {
+                                cand[j][c] = j0 + 64 * u + bit;
+                                cnt[j] = c + 1;
+                            } else {
+                                cnt[j] = -1;  // overflow: the exact scan answers this query
+                            }
+                        }
+                        if (vv < top[j][KK - 1]) {  // keep the kk smallest, ascending
+                            int pos = KK - 1;
+                            while (pos > 0 && top[j][pos - 1] > vv) {
+                                top[j][pos] = top[j][pos - 1];
+                                --pos;
+                            }
+                            top[j][pos] = vv;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    kth = top[j][KK - 1];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // candidates that are still within band of the FINAL kk-th smallest value (the early ones were admitted against looser bounds)
+    for (int j = wave; j < kHamNq; j += kHamWaves) {
+        const long q = q0 + j;
+        if (q >= a.nq) break;
+        const int c = a.q_bad[q] ? -1 : cnt[j];
+        if (lane == 0) a.cand_cnt[q] = c;
+        for (int i = lane; i < c; i += 64) a.cand_id[q * kHamCand + i] = cand[j][i];
+    }
+}
+
+struct HammingRescoreArgs {
+    SelectArgs s;           // s.xq: (nq, d) float64 ids of the queries; s.ref: (n_ref, d) float64 ids; s.hw, s.hw_sum
+    const int* cand_cnt;
+    const int* cand_id;
+    int* fail_list;         // queries for exact_scan_kernel<2> (overflow, bad ids)
+    int* fail_count;
+    int fail_base;
+};
+
+// One wave per query: every lane re-scores candidates in the reference's float64 arithmetic (the same expression, in
+// tree order, as exact_scan_kernel<2>), lane 0 selects by (distance, index) in ascending index order and finishes.
+__global__ void __launch_bounds__(256) hamming_rescore_kernel(HammingRescoreArgs a) {
+    __shared__ double dv[4][kHamCand];
+    __shared__ double hv[4][kHamMaxKK + 2];
+    __shared__ int hi[4][kHamMaxKK + 2];
+    __shared__ int stack[4][2 * kHamMaxKK + 8];
+    const SelectArgs& s = a.s;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * 4 + wave;
+    if (q >= s.nq) return;
+    const int c = a.cand_cnt[q];
+    if (c < s.kk) {  // overflow, ids outside 16 bits (c = -1), or fewer candidates than rows asked for: the full scan
+        if (lane == 0) {
+            const int slot = atomicAdd(a.fail_count, 1);
+            a.fail_list[slot] = a.fail_base + (int)q;
+        }
+        return;
+    }
+    const double* x = s.xq + q * s.d;
+    for (int i = lane; i < c; i += 64) {
+        const double* r = s.ref + (long)a.cand_id[q * kHamCand + i] * s.d;
+        double acc = 0.0;
+        for (int t = 0; t < s.d; ++t) acc = x[t] != r[t] ? acc + s.hw[t] : acc;
+        dv[wave][i] = acc / s.hw_sum;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) {
+        const int KK = s.kk;
+        for (int e = 0; e < KK; ++e) {
+            hv[wave][e] = DBL_MAX;
+            hi[wave][e] = 0;
+        }
+        for (int i = 0; i < c; ++i) {
+            const double v = dv[wave][i];
+            if (v < hv[wave][KK - 1]) sorted_insert_ref(hv[wave], hi[wave], KK, v, a.cand_id[q * kHamCand + i]);
+        }
+        scan_finish_query<2>(s, q, hv[wave], hi[wave], stack[wave]);
+    }
+}
+
+}  // namespace sknnr

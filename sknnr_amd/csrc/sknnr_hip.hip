@@ -32,6 +32,7 @@
 #include "coarse.hip.h"
 #include "coarse2.hip.h"
 #include "exact.hip.h"
+#include "hamming.hip.h"
 
 using namespace sknnr;
 
@@ -241,6 +242,11 @@ struct sknnr_index {
     DevBuf<double> hw;       // weighted-Hamming weights (one per column), set by sknnr_index_set_hamming_weights
     double hw_sum = 0.0;
     bool has_hw = false;
+    // integer pre-filter of the weighted-Hamming search (hamming.hip.h): 16-bit ids / weights, two trees per dword
+    bool h16_ok = false;           // every reference id is an integer in [0, 65535]
+    int h_tp = 0, h_ref_pad = 0;   // tree pairs; reference rows padded to the step of the kernel
+    DevBuf<uint32_t> h_rimg, h_wq, h_qimg;
+    DevBuf<int> h_bad, h_cand_cnt, h_cand_id;
     DevBuf<double> ref64, refT, rn64, y64, mu_dev;  // refT: (d, n_ref) transposed copy for the exact scan
     DevBuf<char> rimg;
     DevBuf<char> rhi2, rlo2;  // coarse2_kernel's image: [hi | |r'|^2] records for the LDS stages, lo fragments apart
@@ -317,6 +323,7 @@ struct sknnr_index {
         perm2.release();
         cell_axes.release(); cell_centre.release(); cell_thr.release(); cell_stage.release();
         qcell.release(); qperm.release(); cell_hist.release(); qlo.release();
+        h_rimg.release(); h_wq.release(); h_qimg.release(); h_bad.release(); h_cand_cnt.release(); h_cand_id.release();
         qimg.release();
         cand_val.release();
         cand_idx.release();
@@ -985,6 +992,33 @@ extern "C" int sknnr_index_set_hamming_weights(sknnr_index* ix, const double* w,
     HIP_TRY(hipMemcpy(ix->hw.p, w, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     ix->hw_sum = total;
     ix->has_hw = true;
+    // the integer image for the pre-filter (hamming.hip.h): reference ids as 16-bit integers, weights scaled to 16 bits
+    ix->h16_ok = false;
+    if (!std::getenv("SKNNR_HAMMING_INT") || std::atoi(std::getenv("SKNNR_HAMMING_INT")) != 0) {
+        const int tp = (n + 1) / 2;
+        const int ref_pad = (int)((ix->n_ref + kHamWaves * 64 - 1) / (kHamWaves * 64) * (kHamWaves * 64));
+        double wmax = 0.0;
+        for (int i = 0; i < n; ++i) wmax = std::max(wmax, w[i]);
+        std::vector<uint32_t> wq((size_t)tp, 0u);
+        for (int i = 0; i < n; ++i) {
+            const uint32_t q16 = (uint32_t)std::min(65535.0, std::floor(w[i] * (65535.0 / wmax) + 0.5));
+            wq[(size_t)i / 2] |= q16 << (16 * (i & 1));
+        }
+        HIP_TRY(ix->h_wq.ensure((size_t)tp));
+        HIP_TRY(hipMemcpy(ix->h_wq.p, wq.data(), (size_t)tp * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(ix->h_rimg.ensure((size_t)tp * ref_pad));
+        DevBuf<int> bad;
+        HIP_TRY(bad.ensure((size_t)ref_pad));
+        hamming_pack_kernel<<<dim3((unsigned)(ref_pad / 256)), dim3(256)>>>(ix->ref64.p, ix->n_ref, ref_pad, n, tp, ix->h_rimg.p, bad.p);
+        HIP_TRY(hipGetLastError());
+        std::vector<int> hb((size_t)ref_pad);
+        HIP_TRY(hipMemcpy(hb.data(), bad.p, (size_t)ref_pad * sizeof(int), hipMemcpyDeviceToHost));
+        bool any_bad = false;
+        for (int v : hb) any_bad = any_bad || v != 0;
+        ix->h_tp = tp;
+        ix->h_ref_pad = ref_pad;
+        ix->h16_ok = !any_bad;
+    }
     return SKNNR_OK;
 }
 
@@ -1694,10 +1728,59 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             HIP_TRY(hipGetLastError());
         }
     }
+    // Weighted Hamming on 16-bit ids: integer pre-filter, float64 re-score of the candidates (hamming.hip.h); the queries
+    // it cannot serve (too many candidates, ids outside 16 bits) join the fail list of the exact scan below
+    const bool ham_int = !coarse && o->formula == SKNNR_FORMULA_HAMMING && ix->h16_ok && kk <= kHamMaxKK;
+    if (ham_int) {
+        const long chunk_q = 1L << 18;  // 768 candidate bytes per query: 200 MB per chunk
+        const long cap_q = std::min(chunk_q, nq);
+        const long cap_pad = (cap_q + 255) / 256 * 256;
+        HIP_TRY(ix->h_qimg.ensure((size_t)ix->h_tp * cap_pad));
+        HIP_TRY(ix->h_bad.ensure((size_t)cap_pad));
+        HIP_TRY(ix->h_cand_cnt.ensure((size_t)cap_q));
+        HIP_TRY(ix->h_cand_id.ensure((size_t)cap_q * kHamCand));
+        HIP_TRY(ix->fail_list.ensure(nq));
+        HIP_TRY(hipMemsetAsync(ix->fail_count.p, 0, 16, st));
+        for (long c0 = 0; c0 < nq; c0 += chunk_q) {
+            const long n = std::min(chunk_q, nq - c0);
+            const long n_pad = (n + 255) / 256 * 256;
+            hamming_pack_kernel<<<dim3((unsigned)(n_pad / 256)), dim3(256), 0, st>>>(xq_call + c0 * ix->d, n, n_pad, ix->d, ix->h_tp,
+                                                                                      ix->h_qimg.p, ix->h_bad.p);
+            HammingArgs ha{};
+            ha.rimg = ix->h_rimg.p;
+            ha.wq = ix->h_wq.p;
+            ha.qimg = ix->h_qimg.p;
+            ha.q_bad = ix->h_bad.p;
+            ha.n_ref = (int)ix->n_ref;
+            ha.n_ref_pad = ix->h_ref_pad;
+            ha.tp = ix->h_tp;
+            ha.nq = n;
+            ha.nq_pad = n_pad;
+            ha.kk = kk;
+            ha.band = (unsigned)ix->d + 2u;
+            ha.cand_cnt = ix->h_cand_cnt.p;
+            ha.cand_id = ix->h_cand_id.p;
+            hamming_coarse_kernel<<<dim3((unsigned)((n + kHamNq - 1) / kHamNq)), dim3(kHamWaves * 64), 0, st>>>(ha);
+            HammingRescoreArgs hr{};
+            hr.s = call;
+            hr.s.xq = xq_call + c0 * ix->d;
+            hr.s.nq = n;
+            hr.s.row_offset = o->row_offset + c0;
+            hr.s.out_dist = d_dist ? d_dist + c0 * o->n_neighbors : nullptr;
+            hr.s.out_idx = d_idx + c0 * o->n_neighbors;
+            hr.cand_cnt = ix->h_cand_cnt.p;
+            hr.cand_id = ix->h_cand_id.p;
+            hr.fail_list = ix->fail_list.p;
+            hr.fail_count = ix->fail_count.p;
+            hr.fail_base = (int)c0;
+            hamming_rescore_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st>>>(hr);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     // One exact scan per call: the rows the finaliser could not certify (call-relative ids), or
     // every row when the call is outside the MFMA envelope.
-    int rc = coarse ? launch_scan(ix, call, ix->fail_list.p, ix->fail_count.p, nq, st)
-                    : launch_scan(ix, call, nullptr, nullptr, nq, st);
+    int rc = (coarse || ham_int) ? launch_scan(ix, call, ix->fail_list.p, ix->fail_count.p, nq, st)
+                                 : launch_scan(ix, call, nullptr, nullptr, nq, st);
     if (rc) return rc;
     if (coarse) {
         // keep a running total on the device; sknnr_get_stats reads it (no sync here)
