@@ -307,7 +307,7 @@ class RefShardedKNN:
     few queries against a large reference set (the query-row sharding of :class:`ShardedKNN` needs at least a
     workgroup of rows per GPU to keep them busy).  The reference's analogue is scikit-learn's parallel-on-Y strategy
     (per-thread heaps over chunks of Y, then ``_parallel_on_Y_synchronize``:
-    SKL/metrics/_pairwise_distances_reduction/_argkmin.pyx.tp:200-261).
+    scikit-learn's ArgKmin, _argkmin.pyx.tp:200-261).
 
     Exactness: the merged list (smallest (value, index) first) is the answer whenever it is unique; rows with an exact
     tie across the last slot are re-scanned over all reference rows by the full engine every rank holds (the small
