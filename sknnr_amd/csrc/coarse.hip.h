@@ -43,6 +43,13 @@ __host__ __device__ constexpr int tile_bytes(int ks) { return 2 * ks * 1024 + 12
 // 32-reference tiles per LDS stage.  One 16-wave workgroup per CU (4 waves per SIMD) shares the
 // stage: two stage buffers + the waves' candidate queues must fit the 160 KiB of LDS.
 __host__ __device__ constexpr int tiles_per_stage(int ks) { return ks <= 2 ? 8 : (ks <= 4 ? 4 : 2); }
+// Query image: every row's B-operand fragments side by side -- [row][part: hi | lo][K-step][K half] 16-byte pieces,
+// 64 KS bytes per row (round 3; rounds 1-2 kept whole 1-KiB MFMA fragments of 32 rows together).  A lane (column
+// `row`, K half `kh`) picks its pieces out of the row's own cache lines, so that bucketed calls, whose q-blocks are
+// made of scattered rows, fetch every line they touch completely (the fragment-major layout cost them 4x the bytes).
+__host__ __device__ constexpr size_t qimg_index(long row, int part, int ks, int s, int kh) {
+    return ((size_t)(row * 2 + part) * ks + s) * 2 + kh;
+}
 // Row of the 32x32 accumulator held in register r of a lane in half h (guide section 3).
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -316,7 +323,7 @@ template <int KS, int M>
 __global__ void __launch_bounds__(coarse_waves(KS, M) * 64, coarse_wps(KS, M))
 coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
               int n_stages,
-              const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments
+              const uint4* __restrict__ qimg,  // [row][2][KS][2] 16-B pieces (qimg_index)
               const double* __restrict__ qnc,  // [n_qblocks*32] |q'|^2 (0 for padding rows)
               float skip_scale,                // 2^-9 * max|r'| * (1 + slack): margin = skip_scale * |q'|
               int n_sentinel,                  // M - (neighbours searched + 1): leading sentinels of the lower lane's list
@@ -342,8 +349,9 @@ coarse_kernel(const char* __restrict__ rimg,   // n_stages * TPS tile records
     for (int qb = 0; qb < NQB; ++qb) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const uint4 uh = qimg[((size_t)((qb0 + qb) * 2 + 0) * KS + s) * 64 + lane];
-            const uint4 ul = qimg[((size_t)((qb0 + qb) * 2 + 1) * KS + s) * 64 + lane];
+            const long row = (long)(qb0 + qb) * 32 + (lane & 31);
+            const uint4 uh = qimg[qimg_index(row, 0, KS, s, lane >> 5)];
+            const uint4 ul = qimg[qimg_index(row, 1, KS, s, lane >> 5)];
             bh[qb][s] = __builtin_bit_cast(half8, uh);
             bl[qb][s] = __builtin_bit_cast(half8, ul);
         }
@@ -514,8 +522,8 @@ coarse_matrix_kernel(const char* __restrict__ rimg, const int* __restrict__ perm
     for (int s = 0; s < KS; ++s) {
         ah[s] = *(const half8*)(tb + (0 * KS + s) * 1024 + lane * 16);
         al[s] = *(const half8*)(tb + (1 * KS + s) * 1024 + lane * 16);
-        bh[s] = __builtin_bit_cast(half8, qimg[((size_t)(qblk * 2 + 0) * KS + s) * 64 + lane]);
-        bl[s] = __builtin_bit_cast(half8, qimg[((size_t)(qblk * 2 + 1) * KS + s) * 64 + lane]);
+        bh[s] = __builtin_bit_cast(half8, qimg[qimg_index((long)qblk * 32 + (lane & 31), 0, KS, s, lane >> 5)]);
+        bl[s] = __builtin_bit_cast(half8, qimg[qimg_index((long)qblk * 32 + (lane & 31), 1, KS, s, lane >> 5)]);
     }
     const int half = lane >> 5;
     floatx16 c0;

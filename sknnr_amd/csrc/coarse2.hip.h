@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 4)
 coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: KS KiB][|r'|^2: 128 B]
                const char* __restrict__ rlo,    // n_stages * TPS records [lo: KS KiB]
                int n_stages,
-               const uint4* __restrict__ qimg,  // [n_qblocks][2][KS][64] 16-B fragments (rows of the chunk)
+               const uint4* __restrict__ qimg,  // [row][2][KS][2] 16-B pieces (qimg_index; rows of the chunk)
                const double* __restrict__ qnc,  // [n_qblocks*32] |q'|^2 (0 for padding rows)
                float skip_scale,                // 2^-9 * max|r'| * (1 + slack): margin = skip_scale * |q'|
                int n_sentinel,                  // M - (neighbours searched + 1)
@@ -173,7 +173,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
                // qperm[p] (null: the row itself).  A workgroup starts its sweep at the stage its middle row's cell names.
                int pos0, const int* __restrict__ qperm, const unsigned char* __restrict__ qcell,
                const int* __restrict__ cell_stage,
-               uint4* __restrict__ qlo) {       // bucketed calls: [n_qblocks][KS][64] lo fragments in POSITION order (scratch)
+               uint4* __restrict__ qlo) {       // scratch: [n_qblocks][KS][64] lo fragments, fragment order by position
     constexpr int TPS = tiles_per_stage2(KS);
     constexpr int TB = tile2_bytes(KS);
     constexpr int STAGE = TPS * TB;
@@ -198,9 +198,9 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         const int mid = qperm[pos0 + (blockIdx.x * WAVES + WAVES / 2) * NQB * 32];
         st0 = __builtin_amdgcn_readfirstlane(cell_stage[qcell[mid]]);
     }
-    // 16-B fragment (part: 0 hi / 1 lo, K-step s) of this lane's column: row r sits in q-block r / 32, column r % 32
+    // 16-B piece (part: 0 hi / 1 lo, K-step s, this lane's K half) of row r
     auto qfrag = [&](int r, int part, int s) {
-        return __builtin_bit_cast(half8, qimg[((size_t)((r >> 5) * 2 + part) * KS + s) * 64 + (lane & 32) + (r & 31)]);
+        return __builtin_bit_cast(half8, qimg[qimg_index(r, part, KS, s, lane >> 5)]);
     };
     auto stage_of = [&](int st) {  // the st-th stage of this workgroup's sweep
         const int i = st0 + st;
@@ -219,14 +219,12 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #pragma unroll
         for (int s = 0; s < KS; ++s) bh[qb][s] = qfrag(r, 0, s);
         qnorm[qb] = (float)sqrt(qnc[r]);
-        // The flush needs the lo fragments of this lane's column again and again: a bucketed call copies them once into
-        // position order (this wave's own 1-KiB blocks, written and later read by the same lanes), so that every later
-        // fetch is one coalesced 1-KiB load instead of 64 scattered 16-byte ones.
-        if (qperm) {
+        // The flush needs the lo fragments of this lane's column again and again: they are copied once into
+        // fragment order by position (this wave's own 1-KiB blocks, written and later read by the same lanes), so that
+        // every later fetch is one coalesced 1-KiB load instead of 64 pieces out of 32 rows' lines.
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
-                qlo[((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane] = __builtin_bit_cast(uint4, qfrag(r, 1, s));
-        }
+        for (int s = 0; s < KS; ++s)
+            qlo[((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane] = __builtin_bit_cast(uint4, qfrag(r, 1, s));
     }
 
 #ifdef SKNNR_V2_BL_RESIDENT  // experiment: the queries' lo fragments stay in registers (12-wave geometry: 168 VGPRs)
@@ -300,9 +298,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #ifdef SKNNR_V2_BL_RESIDENT
             bl[s] = blr[qb][s];
 #else
-            const uint4* src = qperm ? qlo + ((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane
-                                     : qimg + ((size_t)((pos0 / 32 + qb0 + qb) * 2 + 1) * KS + s) * 64 + lane;
-            bl[s] = __builtin_bit_cast(half8, *src);
+            bl[s] = __builtin_bit_cast(half8, qlo[((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane]);
 #endif
         }
         CTR(6, 1);

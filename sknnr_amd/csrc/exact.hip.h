@@ -41,7 +41,7 @@ struct PrepArgs {
     const double* mu;      // (dp) zero padded centre of the coarse image
     double s;              // power-of-two scale of the coarse image
     double* xt;            // (nq, d) transformed rows out, or null
-    uint4* qimg;           // [nq_pad/32][2][ks][64] fragments out, or null (transform only)
+    uint4* qimg;           // [nq_pad][2][ks][2] 16-byte pieces out (qimg_index), or null (transform only)
     double* qnc;           // (nq) out; +inf marks a row whose image overflows f16 (never certified)
     int* status;           // device word, or null: bit 0 = a query value is NaN, bit 1 = infinite
                            // (SKL/utils/validation.py _assert_all_finite, reached from SKL/neighbors/_base.py:838-845)
@@ -95,8 +95,6 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
 
     const long q = q0 + tid;
     const bool live = q < a.nq;
-    const long qb = q >> 5;
-    const int col = (int)(q & 31);
     const int dp = 16 * a.ks;
     const double* xrow = xs + tid * ldx;
     double qn = 0.0;
@@ -142,8 +140,8 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
         }
         if (q < a.nq_pad) {
             const int step = jc >> 1, hh = jc & 1;
-            a.qimg[((size_t)(qb * 2 + 0) * a.ks + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, hi);
-            a.qimg[((size_t)(qb * 2 + 1) * a.ks + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, lo);
+            a.qimg[qimg_index(q, 0, a.ks, step, hh)] = __builtin_bit_cast(uint4, hi);
+            a.qimg[qimg_index(q, 1, a.ks, step, hh)] = __builtin_bit_cast(uint4, lo);
         }
     }
     if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? (overflow ? INFINITY : qn) : 0.0;
@@ -246,8 +244,6 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
         }
     }
     if (!a.qimg) return;
-    const long qb = q >> 5;
-    const int col = (int)(q & 31);
     double qn = 0.0;
     bool overflow = false;
 #pragma unroll
@@ -265,8 +261,8 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
         }
         if (q < a.nq_pad) {
             const int step = jc >> 1, hh = jc & 1;
-            a.qimg[((size_t)(qb * 2 + 0) * KS + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, hi);
-            a.qimg[((size_t)(qb * 2 + 1) * KS + step) * 64 + hh * 32 + col] = __builtin_bit_cast(uint4, lo);
+            a.qimg[qimg_index(q, 0, KS, step, hh)] = __builtin_bit_cast(uint4, hi);
+            a.qimg[qimg_index(q, 1, KS, step, hh)] = __builtin_bit_cast(uint4, lo);
         }
     }
     if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? (overflow ? INFINITY : qn) : 0.0;

@@ -1297,7 +1297,7 @@ int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStrea
     kern<<<dim3((unsigned)(rows / QPB)), dim3(WAVES * 64), sh, st>>>(
         ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
         M - (kk + 1), ix->cand_val.p, ix->cand_idx.p, (int)row0, bucketed ? ix->qperm.p : nullptr,
-        bucketed ? ix->qcell.p : nullptr, bucketed ? ix->cell_stage.p : nullptr, bucketed ? ix->qlo.p : nullptr);
+        bucketed ? ix->qcell.p : nullptr, bucketed ? ix->cell_stage.p : nullptr, ix->qlo.p);
     HIP_TRY(hipGetLastError());
     return SKNNR_OK;
 }
@@ -1558,8 +1558,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     if (coarse && ix->cell_depth > 0) {
         HIP_TRY(ix->qcell.ensure((size_t)cap_pad));
         HIP_TRY(ix->qperm.ensure((size_t)cap_pad));
-        HIP_TRY(ix->qlo.ensure((size_t)(cap_pad / 32) * ix->ks * 64));
     }
+    if (coarse && ix->ks <= 4) HIP_TRY(ix->qlo.ensure((size_t)(cap_pad / 32) * ix->ks * 64));
     if (coarse) {
         HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * coarse_list_len(kk)));
         HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * coarse_list_len(kk)));
