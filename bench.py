@@ -506,6 +506,17 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
     out = {}
     nq, k = q.shape[0], args.k
 
+    # ---- what to expect of the strong-scaling runs (the driver's SCALE file): one rank's share of the job, measured here --
+    # (query-row sharding: no data-path collective before the final all-gather; N = 8 moves 7 x 100 MB per rank over its
+    #  seven xGMI links, ~153 GB/s each: < 1 ms, issued chunk-wise under the kernels)
+    pred = {}
+    for n_gpu in (2, 4, 8):
+        share = nq // n_gpu
+        wall, _ = timed(lambda: eng.kneighbors(q[:share], k, apply_affine=True, deterministic=True), torch, steps=3, warmup=1)
+        pred[str(n_gpu)] = {"rows_per_gpu": share, "ms_per_share": wall * 1e3, "predicted_Mq_s_before_gather": nq / wall / 1e6,
+                            "gather_bytes_received_per_rank": (n_gpu - 1) * share * k * 16}
+    out["strong_scaling_expectation"] = pred
+
     # ---- the headline workload entered from host arrays (PCIe-inclusive; never `value`) ----------
     q_host = q.cpu().numpy()
     wall, (hd, hi) = timed(lambda: eng.kneighbors(q_host, k, apply_affine=True), torch, steps=1, warmup=1)

@@ -71,9 +71,17 @@ __host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb *
 #ifndef SKNNR_V2_M2
 #define SKNNR_V2_M2 1  // one neighbour (lists of 2) on the second-generation kernel, up to 32 features
 #endif
+#ifndef SKNNR_V2_M16
+#define SKNNR_V2_M16 1  // 8 .. 15 neighbours (lists of 16) on the second-generation kernel, up to 32 features, 12 waves
+#endif
 __host__ __device__ constexpr bool coarse2_supported(int ks, int m) {
-    return (m == 6 && ks <= 4) || (m == 8 && ks <= 3) || (SKNNR_V2_M2 && m == 2 && ks <= 2);
+    return (m == 6 && ks <= 4) || (m == 8 && ks <= 3) || (SKNNR_V2_M2 && m == 2 && ks <= 2) || (SKNNR_V2_M16 && m == 16 && ks <= 2);
 }
+// waves per workgroup of the bulk launch: 16 (4 per SIMD, <= 128 VGPRs); lists of 16 need 12 (3 per SIMD, <= 168)
+#ifndef SKNNR_V2_M16_WAVES
+#define SKNNR_V2_M16_WAVES 12
+#endif
+__host__ __device__ constexpr int coarse2_waves(int ks, int m) { return m == 16 ? SKNNR_V2_M16_WAVES : kCoarse2Waves; }
 
 // sum_j x[j] * y[j] over one 8-element fragment, f32 accumulate (v_dot2c_f32_f16)
 __device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc) {
@@ -159,7 +167,7 @@ __device__ __forceinline__ void tile_issue_and_test(floatx16& a, floatx16& c, co
 // last, thinly filled round of workgroups and for small calls: spread over four times as many CUs with one wave per
 // SIMD, where a wave no longer shares its matrix pipe (host side: launch_coarse2_ks).
 template <int KS, int M, int WAVES = kCoarse2Waves>
-__global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 4)
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : (WAVES == 8 || M > 8 ? 2 : 4))
 coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: KS KiB][|r'|^2: 128 B]
                const char* __restrict__ rlo,    // n_stages * TPS records [lo: KS KiB]
                int n_stages,

@@ -1308,18 +1308,19 @@ int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStrea
 // the CUs' worth) go to 4-wave workgroups instead: four times as many CUs, one wave per SIMD.
 template <int KS, int M>
 int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
-    constexpr long QPB = kCoarse2Waves * kCoarse2Nqb * 32;
+    constexpr int BULK_WAVES = coarse2_waves(KS, M);
+    constexpr long QPB = BULK_WAVES * kCoarse2Nqb * 32;
     static const bool split = [] {
         const char* e = std::getenv("SKNNR_COARSE_TAIL");
         return !(e && std::atoi(e) == 0);
     }();
     const long n_wg = nq_pad / QPB;
     long tail_wg = n_wg % kCusPerDevice;
-    if (!split || tail_wg > kCusPerDevice / (kCoarse2Waves / kCoarse2TailWaves)) tail_wg = 0;
+    if (!split || tail_wg > kCusPerDevice / (BULK_WAVES / kCoarse2TailWaves)) tail_wg = 0;
     const long bulk_rows = (n_wg - tail_wg) * QPB;
     ix->bulk_rows_done = 0;
     if (bulk_rows > 0) {
-        int rc = launch_coarse2_waves<KS, M, kCoarse2Waves>(ix, 0, bulk_rows, kk, st);
+        int rc = launch_coarse2_waves<KS, M, BULK_WAVES>(ix, 0, bulk_rows, kk, st);
         if (rc) return rc;
         if (tail_wg > 0 && ix->ev_fork) {  // the caller finalises these rows beside the thin round
             if (ix->ev_bulk_end) {  // the timed region ends here: the thin round shares the device from now on
@@ -1354,6 +1355,8 @@ int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t
     if (ix->ks == 1 && m_list == 8) return launch_coarse2_ks<1, 8>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 6) return launch_coarse2_ks<2, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 8) return launch_coarse2_ks<2, 8>(ix, nq_pad, kk, st);
+    if (ix->ks == 1 && m_list == 16) return launch_coarse2_ks<1, 16>(ix, nq_pad, kk, st);
+    if (ix->ks == 2 && m_list == 16) return launch_coarse2_ks<2, 16>(ix, nq_pad, kk, st);
 #ifndef SKNNR_DEV_ONLY_KS2_M6
     if (ix->ks == 3 && m_list == 6) return launch_coarse2_ks<3, 6>(ix, nq_pad, kk, st);
     if (ix->ks == 3 && m_list == 8) return launch_coarse2_ks<3, 8>(ix, nq_pad, kk, st);
