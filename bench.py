@@ -112,14 +112,24 @@ def fit_space(kind, n_ref, d_in, t, device, n_components=None, x_ref=None):
 
 
 def timed(fn, torch, steps=2, warmup=1):
+    """Mean wall time of `fn()`.  The previous call's result is released BEFORE the clock starts: returning 800 MB of
+    host arrays to the OS takes ~35 ms, which belongs to the caller's `del`, not to the call being timed (the call's
+    own allocation and first-touch page faults stay inside)."""
+    out = None
     for _ in range(warmup):
+        out = None
         out = fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    total = 0.0
     for _ in range(steps):
+        out = None
+        t0 = time.perf_counter()
         out = fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps, out
+        total += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()  # (device-resident calls are asynchronous: one wait for all of them, as before)
+    total += time.perf_counter() - t0
+    return total / steps, out
 
 
 def oracle_slice_check(x_ref_t, affine, q_raw_slice, k, dist, idx, formula="expanded", pred=None, y=None, weights=None):
@@ -519,8 +529,9 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
 
     # ---- the headline workload entered from host arrays (PCIe-inclusive; never `value`) ----------
     q_host = q.cpu().numpy()
-    wall, (hd, hi) = timed(lambda: eng.kneighbors(q_host, k, apply_affine=True), torch, steps=1, warmup=1)
+    wall, (hd, hi) = timed(lambda: eng.kneighbors(q_host, k, apply_affine=True), torch, steps=2, warmup=1)
     out["host_to_host_Mq_s"] = nq / wall / 1e6
+    out["host_to_host_note"] = "numpy rows in, fresh numpy (dist, idx) out: mean of 2 calls after 1 warm-up, allocation and first-touch faults of the outputs included"
     tile = 1_000_000
     d_st = np.empty((nq, k))
     i_st = np.empty((nq, k), dtype=np.int64)
@@ -531,7 +542,7 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
                 s.push(q_host[a:a + tile], out_idx=i_st[a:a + tile], out_dist=d_st[a:a + tile])
         return None
 
-    wall, _ = timed(stream_run, torch, steps=1, warmup=0)
+    wall, _ = timed(stream_run, torch, steps=1, warmup=1)  # (the warm-up pass touches the caller-owned output arrays)
     out["stream_Mq_s"] = nq / wall / 1e6
     out["stream_note"] = (f"{-(-nq // tile)} pushes of {tile} rows through sknnr_stream_*; equals the one-call result: "
                           f"{bool(np.array_equal(i_st, hi) and np.array_equal(d_st, hd))}")
@@ -546,7 +557,7 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
     t0 = time.perf_counter()
     est = sknnr_amd.GNNRegressor(n_neighbors=k).fit(x_ref, y)
     est_fit = time.perf_counter() - t0
-    wall, _ = timed(lambda: est.kneighbors(q_host), torch, steps=1, warmup=1)
+    wall, _ = timed(lambda: est.kneighbors(q_host), torch, steps=2, warmup=1)
     out["estimator_Mq_s"] = nq / wall / 1e6
     out["estimator_note"] = (f"GNNRegressor(n_neighbors={k}).fit in {est_fit:.2f} s (incl. independent prediction), "
                              "kneighbors(X_numpy) wall: sklearn validate_data (no host finiteness pass) + host pipeline")
