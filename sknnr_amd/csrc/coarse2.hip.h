@@ -93,6 +93,34 @@ __device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc)
     return acc;
 }
 
+// The (M + E)-th smallest entry of the union of the two sorted M-lists owned by lanes l and l+32 (E >= 1: a rank beyond
+// the length of one list -- lists of 16 serve up to 30 neighbours):
+//     max(a_{E-1}, b_{E-1}, max_{i = E .. M-1} min(a_i, b_{M+E-1-i}))
+// (k-th smallest of a union = max over i + j = k - 1 of min(a_i, b_j), entries past the end of a list counting as +inf).
+// Both lanes get the same value.  For this to bound what the LISTS let go of as well as what the skip test rejects, the
+// two lists of a query are kept as one pool of 2 M entries (flush: what one list displaces is offered to the other unless
+// it is already above the threshold), so that everything dropped is >= the final threshold or >= the larger of the two
+// last entries, which no rank of the union exceeds.
+template <int M, int E>
+__device__ __forceinline__ float pair_union_rank(const float (&vals)[M]) {
+    if constexpr (E == 0) {
+        return pair_union_rank_m<M>(vals);
+    } else {
+        static_assert(E >= 1 && E < M, "rank between M + 1 and 2 M - 1");
+        float u = fmaxf(vals[E - 1], __shfl_xor(vals[E - 1], 32, 64));
+#pragma unroll
+        for (int i = E; i < M; ++i) u = fmaxf(u, fminf(vals[i], __shfl_xor(vals[M + E - 1 - i], 32, 64)));
+        return u;
+    }
+}
+// Ranks beyond a list of 16: 22, 27 and 31 (one kernel instance each), for 16 .. 20, 21 .. 25 and 26 .. 30 neighbours
+// searched.  A rank above neighbours + 1 is a looser threshold, never a wrong one, and the certificate likes the slack:
+// the gaps between a query's consecutive neighbour distances shrink with the rank.
+__host__ __device__ constexpr int coarse2_rank_extra(int m_list, int kk) {
+    return kk + 1 <= m_list ? 0 : (kk + 2 <= m_list + 6 ? 6 : (kk + 2 <= m_list + 11 ? 11 : 15));
+}
+constexpr int kCoarse2MaxKK16 = 30;
+
 // The skip test of a unit: the minimum of its sixteen main values, as raw instructions (hipcc neither interleaves
 // independent VALU work between dependent MFMAs nor sees through the min instructions, so the tile step below is
 // written out in asm: MFMAs back to back, the tree of the first unit behind the MFMAs of the second -- about four
@@ -166,7 +194,8 @@ __device__ __forceinline__ void tile_issue_and_test(floatx16& a, floatx16& c, co
 // WAVES = 16 (one workgroup of 1024 query rows per CU) for the bulk of a call; WAVES = 4 (256 rows) for the rows of a
 // last, thinly filled round of workgroups and for small calls: spread over four times as many CUs with one wave per
 // SIMD, where a wave no longer shares its matrix pipe (host side: launch_coarse2_ks).
-template <int KS, int M, int WAVES = kCoarse2Waves>
+// E > 0: thresholds of rank M + E (pair_union_rank), the two lists of a query kept as one pool, no sentinels.
+template <int KS, int M, int WAVES = kCoarse2Waves, int E = 0>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : (WAVES == 8 || M > 8 ? 2 : 4))
 coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: KS KiB][|r'|^2: 128 B]
                const char* __restrict__ rlo,    // n_stages * TPS records [lo: KS KiB]
@@ -174,7 +203,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
                const uint4* __restrict__ qimg,  // [row][2][KS][2] 16-B pieces (qimg_index; rows of the chunk)
                const double* __restrict__ qnc,  // [n_qblocks*32] |q'|^2 (0 for padding rows)
                float skip_scale,                // 2^-9 * max|r'| * (1 + slack): margin = skip_scale * |q'|
-               int n_sentinel,                  // M - (neighbours searched + 1)
+               int n_sentinel,                  // M - (neighbours searched + 1); E > 0: 0
                float* __restrict__ cand_val,    // [n_qblocks*32][2][M]
                int* __restrict__ cand_idx,
                // Query bucketing (bucket.hip.h): the kernel works on POSITIONS pos0 .. of the chunk; position p holds row
@@ -310,6 +339,8 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #endif
         }
         CTR(6, 1);
+        unsigned long long any_aside = 0;  // (E > 0) lanes that set an entry aside for the partner's list
+        int n_iter = 0;
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt[qb]) != 0; ++i) {
             CTR(7, 1);
             CTR(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < cnt[qb])));
@@ -369,10 +400,52 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #endif
             const float from_partner = __shfl_xor(part_par, 32, 64);  // the partner's half of MY entry
             const float cv = ev + (part_own + from_partner);
-            if (active && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, pos_own);
+            if constexpr (E == 0) {
+                if (active && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, pos_own);
+            } else {
+                // One pool of 2 M entries per query: what this lane's list lets go of -- the entry an insertion displaces,
+                // or the candidate itself -- is set aside for the partner's list (in the queue slot this trip has
+                // read), unless it is no smaller than `loose`, which stays above the final threshold of the
+                // query (every later `tight` is at most this one, and loose >= tight): such an entry may go for good.
+                // (Lists that are not full let go of FLT_MAX.)
+                float out_v = FLT_MAX;
+                int out_i = -1;
+                if (active) {
+                    if (cv < vals[qb][M - 1]) {
+                        out_v = vals[qb][M - 1];
+                        out_i = idxs[qb][M - 1];
+                        list_insert<M>(vals[qb], idxs[qb], cv, pos_own);
+                    } else {
+                        out_v = cv;
+                        out_i = pos_own;
+                    }
+                }
+                // (every lane writes the slot it has just read, FLT_MAX when it has nothing to pass on: no per-lane
+                //  count to keep alive across the sweep)
+                const bool offer = out_v < loose[qb];
+                any_aside |= __builtin_amdgcn_ballot_w64(offer);
+                queue_store(qlane + i * 512, offer ? out_v : FLT_MAX, out_i);
+                n_iter = i + 1;
+            }
+        }
+        if constexpr (E > 0) {
+            // ... and every lane takes what its partner set aside.  In the steady state the last entry of a list lies
+            // above the rank the threshold is taken at, nothing is set aside and this is one scalar test.  What is
+            // dropped HERE has sixteen entries below it in both lists: it is >= the 32nd smallest of the pool, which no
+            // rank of the union exceeds.
+            if (any_aside != 0) {
+                const unsigned qpartner = half ? qlane - 256u : qlane + 256u;
+                for (int j = 0; j < n_iter; ++j) {
+                    const unsigned long long e = queue_load(qpartner + j * 512);
+                    const float in_v = __uint_as_float((unsigned)e);
+                    if (__builtin_amdgcn_ballot_w64(in_v < vals[qb][M - 1]) != 0) {
+                        if (in_v < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], in_v, (int)(e >> 32));
+                    }
+                }
+            }
         }
         cnt[qb] = 0;
-        const float tight = pair_union_rank_m<M>(vals[qb]) + margin[qb];
+        const float tight = pair_union_rank<M, E>(vals[qb]) + margin[qb];
         loose[qb] = loose[qb] != loose[qb] ? loose[qb] : min2f(loose[qb], tight);  // (NaN = poisoned: stays)
         TSTAMP(2);  // flush
     };
@@ -460,7 +533,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         for (int qb = 0; qb < NQB; ++qb) {
             // J distinct rows have main values <= the J-th smallest seed; their corrected values are at most
             // `margin` larger: a valid bound on the J-th smallest corrected value of the whole sweep
-            const float seed = pair_union_rank_m<M>(vals[qb]);
+            const float seed = pair_union_rank<M, E>(vals[qb]);
             loose[qb] = seed < FLT_MAX ? seed + 2.0f * margin[qb] : FLT_MAX;
             reset_lists(qb);
         }

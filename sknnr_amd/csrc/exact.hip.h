@@ -376,6 +376,8 @@ struct FinalizeArgs {
     const int* cand_idx;    // image positions (coarse.hip.h sweeps the norm-ordered image)
     const int* perm;        // image position -> reference row
     int m_list;             // entries per lane list written by the coarse kernel (<= M)
+    int rank_extra;         // E: the pre-filter's thresholds were of rank m_list + E of the two lists (coarse2.hip.h,
+                            //    pair_union_rank; 0: rank m_list)
     const double* qnc;      // (nq)
     double inv_s2;          // 1 / s^2
     double s2;              // s^2
@@ -592,10 +594,17 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     // Bound on everything outside the lists: the m_list-th smallest entry of the two lists together
     // (sentinels included), max_i min(a_i, b_{m-1-i}) -- the value the pre-filter's rejections were
     // tested against last (coarse.hip.h, pair_union_rank_m).
+    // With rank_extra = E > 0 the rejections were tested against rank m + E,
+    //     max(a_{E-1}, b_{E-1}, max_{i = E .. m-1} min(a_i, b_{m+E-1-i})),
+    // and the two lists were kept as one pool (coarse2.hip.h, pair_union_rank): what they dropped is >= the final
+    // threshold or >= the larger of their last entries, which no rank of the union exceeds.
+    const int ex = a.rank_extra;
     const float cv_raw = has_slot ? cv : INFINITY;
-    const int partner = M + (has_slot ? a.m_list - 1 - slot : 0);
+    const bool paired = has_slot && slot >= ex;
+    const int partner = M + (paired ? a.m_list + ex - 1 - slot : 0);
     const float cv_partner = __shfl(cv_raw, partner, LPQ);
-    const double t_pair = (list == 0 && has_slot) ? (double)fminf(cv_raw, cv_partner) : -INFINITY;
+    double t_pair = (list == 0 && paired) ? (double)fminf(cv_raw, cv_partner) : -INFINITY;
+    if (ex > 0 && has_slot && slot == ex - 1) t_pair = (double)cv_raw;
     const double t_min = group_max<LPQ>(t_pair, c);
     // true d2 of every outside row >= (qn + t_min - eps) / s^2; the value the reference ranks it by is at
     // most `noise` below that.  qn = +inf (image overflow) and NaN inputs fail the comparison.

@@ -1290,13 +1290,22 @@ int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStrea
     constexpr size_t sh = 2 * (size_t)tiles_per_stage2(KS) * tile2_bytes(KS) + (size_t)WAVES * queue2_bytes_per_wave();
     static_assert(kRowQuantum % QPB == 0, "query rows are padded to multiples of kRowQuantum");
     static_assert(sh <= 160 * 1024, "LDS budget");
-    auto kern = coarse2_kernel<KS, M, WAVES>;
+    // more neighbours than a list holds (M = 16, kk = 16 .. 30): thresholds of rank M + E, no sentinels
+    const int extra = coarse2_rank_extra(M, kk);
+    if (extra != 0 && (M != 16 || kk > kCoarse2MaxKK16)) return fail(SKNNR_ERR_UNSUPPORTED, "lists of %d cannot serve %d neighbours", M, kk);
+    auto kern = coarse2_kernel<KS, M, WAVES, 0>;
+    if constexpr (M == 16) {
+        if (extra == 6) kern = coarse2_kernel<KS, M, WAVES, 6>;
+        else if (extra == 11) kern = coarse2_kernel<KS, M, WAVES, 11>;
+        else if (extra == 15) kern = coarse2_kernel<KS, M, WAVES, 15>;
+    }
+    const bool big = extra != 0;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     // positions [row0, row0 + rows) of the chunk (bucketed calls: position -> row through qperm, else the row itself)
     const bool bucketed = ix->cell_depth > 0;
     kern<<<dim3((unsigned)(rows / QPB)), dim3(WAVES * 64), sh, st>>>(
         ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
-        M - (kk + 1), ix->cand_val.p, ix->cand_idx.p, (int)row0, bucketed ? ix->qperm.p : nullptr,
+        big ? 0 : M - (kk + 1), ix->cand_val.p, ix->cand_idx.p, (int)row0, bucketed ? ix->qperm.p : nullptr,
         bucketed ? ix->qcell.p : nullptr, bucketed ? ix->cell_stage.p : nullptr, ix->qlo.p);
     HIP_TRY(hipGetLastError());
     return SKNNR_OK;
@@ -1369,6 +1378,18 @@ int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t
 // cheap.  kk > 31 is outside the MFMA envelope (exact scan for the whole call).
 constexpr int kCoarseMaxKK = 31;
 int coarse_list_len(int kk) { return kk <= 1 ? 2 : (kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32))); }
+// ... for this handle: 16 .. 30 neighbours keep lists of 16 where the second-generation kernel serves them, with
+// thresholds of rank 22 / 27 / 31 over the two lists of a query kept as one pool (coarse2.hip.h, pair_union_rank) --
+// against lists of 32 on the first-generation kernel at half the rate or less.
+int coarse_list_len(const sknnr_index* ix, int kk) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("SKNNR_V2_BIG_K");
+        return !(e && std::atoi(e) == 0);
+    }();
+    if (enabled && kk > 15 && kk <= kCoarse2MaxKK16 && use_coarse2(ix, 16)) return 16;
+    return coarse_list_len(kk);
+}
+int coarse_rank_extra(int m_list, int kk) { return coarse2_rank_extra(m_list, kk); }
 
 #ifdef SKNNR_DEV_ONLY_KS2_M6  // development builds: only the bench's instantiation (fast compile)
 int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
@@ -1551,7 +1572,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         HIP_TRY(ix->xt.ensure((size_t)nq * ix->d));
         xq_call = ix->xt.p;
     }
-    const long chunk = chunk_rows(ix->ks, coarse_list_len(kk));
+    const long chunk = chunk_rows(ix->ks, coarse_list_len(ix, kk));
     const long cap = std::min(chunk, nq);
     const long cap_pad = (cap + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
     if (coarse || affine) {
@@ -1564,8 +1585,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     }
     if (coarse && ix->ks <= 4) HIP_TRY(ix->qlo.ensure((size_t)(cap_pad / 32) * ix->ks * 64));
     if (coarse) {
-        HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * coarse_list_len(kk)));
-        HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * coarse_list_len(kk)));
+        HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * coarse_list_len(ix, kk)));
+        HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * coarse_list_len(ix, kk)));
         HIP_TRY(ix->fail_list.ensure(nq));
         HIP_TRY(hipMemsetAsync(ix->fail_count.p, 0, 16, st));
     }
@@ -1614,7 +1635,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         const long n = std::min(chunk, nq - c0);
         const long n_pad = (n + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
         const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
-        const bool bucketed = coarse && ix->cell_depth > 0 && use_coarse2(ix, coarse_list_len(kk));
+        const bool bucketed = coarse && ix->cell_depth > 0 && use_coarse2(ix, coarse_list_len(ix, kk));
         bool cells_done = false;
         if (coarse || affine) {
             int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st, check_finite, bucketed, &cells_done);
@@ -1629,7 +1650,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             ct.coarse.emplace_back(e0, e1);
         }
         auto& ev = ct.coarse[ct.coarse_used++];
-        const bool v2 = use_coarse2(ix, coarse_list_len(kk));
+        const bool v2 = use_coarse2(ix, coarse_list_len(ix, kk));
         if (bucketed) {
             // cell of every row, rows bucketed by cell: position -> row (bucket.hip.h)
             CellArgs ca{};
@@ -1665,8 +1686,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
                                   : (long)ix->n_stages * tiles_per_stage(ix->ks);
             ix->stats.mfma_executed_ratio = (double)tiles * 32.0 * (16.0 * ix->ks) / ((double)ix->n_ref * ix->d);
         }
-        int rc = v2 ? launch_coarse2(ix, n_pad, coarse_list_len(kk), kk, st)
-                    : launch_coarse(ix, n_pad, coarse_list_len(kk), kk, st);
+        int rc = v2 ? launch_coarse2(ix, n_pad, coarse_list_len(ix, kk), kk, st)
+                    : launch_coarse(ix, n_pad, coarse_list_len(ix, kk), kk, st);
         if (rc) return rc;
         if (ix->ev_bulk_end) HIP_TRY(hipEventRecord(ev.second, st));  // (no fork: the whole pre-filter is timed)
         ix->ev_bulk_end = nullptr;
@@ -1684,7 +1705,8 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         f.perm = v2 ? ix->perm2.p : ix->perm.p;
         f.qnc = ix->qnc.p;
         f.qperm = bucketed ? ix->qperm.p : nullptr;
-        f.m_list = coarse_list_len(kk);
+        f.m_list = coarse_list_len(ix, kk);
+        f.rank_extra = coarse_rank_extra(f.m_list, kk);
         f.inv_s2 = 1.0 / (ix->s * ix->s);
         f.s2 = ix->s * ix->s;
         f.inv_s = 1.0 / ix->s;
