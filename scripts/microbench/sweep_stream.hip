@@ -16,6 +16,19 @@
 
 using namespace sknnr;
 
+// KS = 1 with |r'|^2 carried in spare K slots of the operands (D_t <= 13): the C operand is the constant 0, no
+// accumulator loads from LDS.
+__device__ __forceinline__ void tile_issue_and_test_zero(floatx16& a, floatx16& c, const half8& h, const half8& p, const half8& q,
+                                                         float (&g)[5], float& m) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %[a], %[h0], %[p0], 0\n\t" : [a] "=&v"(a) : [h0] "v"(h), [p0] "v"(p));
+    asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[h0], %[q0], 0\n\t"
+                 "s_nop 7\n\ts_nop 3\n\t"
+                 : [c] "=&v"(c)
+                 : [h0] "v"(h), [q0] "v"(q), "v"(a));
+    const floatx16& x = a;
+    asm volatile(SKNNR_TREE_A SKNNR_TREE_B : SKNNR_TREE_OUT : SKNNR_TREE_IN);
+}
+
 template <int KS, int WAVES, int NQB, int MODE>
 __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
 sweep_kernel(const char* __restrict__ rhi, int n_stages, const uint4* __restrict__ qimg, float thr, float* out,
@@ -69,6 +82,25 @@ sweep_kernel(const char* __restrict__ rhi, int n_stages, const uint4* __restrict
                 load_hi(tb, ah);
                 load_c(tb, acc1);
                 tile_issue_and_test<KS>(acc0, acc1, ah, bh[0], bh[1], g, m1);
+                test(m1, 0);
+                step_test_only(acc1, g, m1);
+                test(m1, 1);
+            }
+            __syncthreads();
+        }
+    } else if constexpr (MODE == 2) {
+        static_assert(MODE != 2 || (NQB == 2 && KS == 1), "zero-C step: one K-step, two q-blocks");
+        for (int st = 0; st < n_stages; ++st) {
+            const char* cur = smem + (st & 1) * STAGE;
+            if (st + 1 < n_stages) stage_copy(rhi + (size_t)(st + 1) * STAGE, smem + ((st + 1) & 1) * STAGE, STAGE, wave, lane, WAVES);
+            float g[5], m1;
+#pragma unroll 1
+            for (int t = 0; t < TPS; ++t) {
+                const char* tb = cur + t * TB;
+                floatx16 acc0, acc1;
+                half8 ah[KS];
+                load_hi(tb, ah);
+                tile_issue_and_test_zero(acc0, acc1, ah[0], bh[0][0], bh[1][0], g, m1);
                 test(m1, 0);
                 step_test_only(acc1, g, m1);
                 test(m1, 1);
@@ -192,6 +224,7 @@ int main() {
         run<2, 8, 4, 1>("pipelined", n_stages, 8);
         run<2, 4, 4, 1>("pipelined", n_stages, 8);
         run<1, 16, 2, 0>("shipped tile step", n_stages, 8);
+        run<1, 16, 2, 2>("zero-C tile step", n_stages, 8);
         run<1, 12, 2, 1>("pipelined", n_stages, 8);
         run<1, 12, 3, 1>("pipelined", n_stages, 8);
         run<4, 16, 2, 0>("shipped tile step", n_stages, 4);
