@@ -21,6 +21,9 @@ cfgs = {
     "sorted": lambda: bench.extra_config("sorted", "gnn", 10_000_000, 50_000, 32, 5, torch, 0,
                                          x_ref=(lambda s: np.ascontiguousarray(s[np.argsort(s[:, 0])]))(synth.make_features(50_000, 32, seed=0))),
     "k10": lambda: bench.extra_config("k10", "gnn", 4_000_000, 50_000, 32, 10, torch, 0),
+    "k7": lambda: bench.extra_config("k7", "gnn", 10_000_000, 50_000, 32, 7, torch, 0),
+    "k7d64": lambda: bench.extra_config("k7d64", "mahalanobis", 4_000_000, 50_000, 64, 7, torch, 0),
+    "k14": lambda: bench.extra_config("k14", "gnn", 4_000_000, 50_000, 32, 14, torch, 0),
     "k16": lambda: bench.extra_config("k16", "gnn", 2_000_000, 50_000, 32, 16, torch, 0),
     "k25": lambda: bench.extra_config("k25", "gnn", 2_000_000, 50_000, 32, 25, torch, 0),
     "k30": lambda: bench.extra_config("k30", "gnn", 2_000_000, 50_000, 32, 30, torch, 0),

@@ -106,20 +106,27 @@ __device__ __forceinline__ float pair_union_rank(const float (&vals)[M]) {
     if constexpr (E == 0) {
         return pair_union_rank_m<M>(vals);
     } else {
-        static_assert(E >= 1 && E < M, "rank between M + 1 and 2 M - 1");
+        static_assert(E >= 1 && E <= M, "rank between M + 1 and 2 M");
         float u = fmaxf(vals[E - 1], __shfl_xor(vals[E - 1], 32, 64));
 #pragma unroll
         for (int i = E; i < M; ++i) u = fmaxf(u, fminf(vals[i], __shfl_xor(vals[M + E - 1 - i], 32, 64)));
         return u;
     }
 }
-// Ranks beyond a list of 16: 22, 27 and 31 (one kernel instance each), for 16 .. 20, 21 .. 25 and 26 .. 30 neighbours
-// searched.  A rank above neighbours + 1 is a looser threshold, never a wrong one, and the certificate likes the slack:
-// the gaps between a query's consecutive neighbour distances shrink with the rank.
+// Ranks beyond the length of a list (one kernel instance each), by neighbours searched (kk):
+//   lists of 6 : rank  9 for kk = 6 .. 7
+//   lists of 8 : rank 12 for kk = 8 .. 10, 15 for 11 .. 13, 16 (the whole pool) for 14 .. 15
+//   lists of 16: rank 22 for kk = 16 .. 20, 27 for 21 .. 25, 31 for 26 .. 30, 32 for 31
+// A rank above kk + 1 is a looser threshold, never a wrong one, and the certificate likes the slack: the gaps between a
+// query's consecutive neighbour distances shrink with the rank.
 __host__ __device__ constexpr int coarse2_rank_extra(int m_list, int kk) {
-    return kk + 1 <= m_list ? 0 : (kk + 2 <= m_list + 6 ? 6 : (kk + 2 <= m_list + 11 ? 11 : 15));
+    if (kk + 1 <= m_list) return 0;
+    if (m_list == 6) return 3;
+    if (m_list == 8) return kk <= 10 ? 4 : (kk <= 13 ? 7 : 8);
+    return kk <= 20 ? 6 : (kk <= 25 ? 11 : (kk <= 30 ? 15 : 16));
 }
-constexpr int kCoarse2MaxKK16 = 30;
+constexpr int kCoarse2MaxKK6 = 7, kCoarse2MaxKK8 = 15;
+constexpr int kCoarse2MaxKK16 = 31;
 
 // The skip test of a unit: the minimum of its sixteen main values, as raw instructions (hipcc neither interleaves
 // independent VALU work between dependent MFMAs nor sees through the min instructions, so the tile step below is

@@ -1290,14 +1290,22 @@ int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStrea
     constexpr size_t sh = 2 * (size_t)tiles_per_stage2(KS) * tile2_bytes(KS) + (size_t)WAVES * queue2_bytes_per_wave();
     static_assert(kRowQuantum % QPB == 0, "query rows are padded to multiples of kRowQuantum");
     static_assert(sh <= 160 * 1024, "LDS budget");
-    // more neighbours than a list holds (M = 16, kk = 16 .. 30): thresholds of rank M + E, no sentinels
+    // more neighbours than a list holds: thresholds of rank M + E, no sentinels (coarse2_rank_extra)
     const int extra = coarse2_rank_extra(M, kk);
-    if (extra != 0 && (M != 16 || kk > kCoarse2MaxKK16)) return fail(SKNNR_ERR_UNSUPPORTED, "lists of %d cannot serve %d neighbours", M, kk);
+    if (extra != 0 && !((M == 16 && kk <= kCoarse2MaxKK16) || (M == 8 && kk <= kCoarse2MaxKK8) || (M == 6 && kk <= kCoarse2MaxKK6)))
+        return fail(SKNNR_ERR_UNSUPPORTED, "lists of %d cannot serve %d neighbours", M, kk);
     auto kern = coarse2_kernel<KS, M, WAVES, 0>;
     if constexpr (M == 16) {
         if (extra == 6) kern = coarse2_kernel<KS, M, WAVES, 6>;
         else if (extra == 11) kern = coarse2_kernel<KS, M, WAVES, 11>;
         else if (extra == 15) kern = coarse2_kernel<KS, M, WAVES, 15>;
+        else if (extra == 16) kern = coarse2_kernel<KS, M, WAVES, 16>;
+    } else if constexpr (M == 8) {
+        if (extra == 4) kern = coarse2_kernel<KS, M, WAVES, 4>;
+        else if (extra == 7) kern = coarse2_kernel<KS, M, WAVES, 7>;
+        else if (extra == 8) kern = coarse2_kernel<KS, M, WAVES, 8>;
+    } else if constexpr (M == 6) {
+        if (extra == 3) kern = coarse2_kernel<KS, M, WAVES, 3>;
     }
     const bool big = extra != 0;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
@@ -1378,15 +1386,20 @@ int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t
 // cheap.  kk > 31 is outside the MFMA envelope (exact scan for the whole call).
 constexpr int kCoarseMaxKK = 31;
 int coarse_list_len(int kk) { return kk <= 1 ? 2 : (kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32))); }
-// ... for this handle: 16 .. 30 neighbours keep lists of 16 where the second-generation kernel serves them, with
-// thresholds of rank 22 / 27 / 31 over the two lists of a query kept as one pool (coarse2.hip.h, pair_union_rank) --
-// against lists of 32 on the first-generation kernel at half the rate or less.
+// ... for this handle: where the second-generation kernel serves them, 6 .. 7 neighbours keep lists of 6, 8 .. 15 lists of
+// 8 and 16 .. 31 lists of 16, with thresholds of a rank beyond one list over the two lists of a query kept as one pool
+// (coarse2.hip.h, pair_union_rank, coarse2_rank_extra) -- shorter lists are cheaper to keep, lists of 8 run with 16 waves
+// per CU and no spills where lists of 16 need 12 waves, and lists of 32 exist on the first-generation kernel only.
 int coarse_list_len(const sknnr_index* ix, int kk) {
-    static const bool enabled = [] {
-        const char* e = std::getenv("SKNNR_V2_BIG_K");
-        return !(e && std::atoi(e) == 0);
+    static const int enabled = [] {
+        const char* e = std::getenv("SKNNR_V2_BIG_K");  // 0: off, 1: lists of 16 only, 2: and lists of 8, default: all
+        return e ? std::atoi(e) : 3;
     }();
-    if (enabled && kk > 15 && kk <= kCoarse2MaxKK16 && use_coarse2(ix, 16)) return 16;
+    // (6 .. 7 neighbours: lists of 8 hold them where that kernel exists -- measured equal, 169 vs 169 Mq/s at 10M x 50k x 32,
+    //  k = 7 -- and lists of 6 serve four K-steps, where lists of 8 would spill: 84 -> 95 Mq/s at 64 features)
+    if (enabled >= 3 && kk > 5 && kk <= kCoarse2MaxKK6 && !use_coarse2(ix, 8) && use_coarse2(ix, 6)) return 6;
+    if (enabled >= 2 && kk > 7 && kk <= kCoarse2MaxKK8 && use_coarse2(ix, 8)) return 8;
+    if (enabled >= 1 && kk > 15 && kk <= kCoarse2MaxKK16 && use_coarse2(ix, 16)) return 16;
     return coarse_list_len(kk);
 }
 int coarse_rank_extra(int m_list, int kk) { return coarse2_rank_extra(m_list, kk); }

@@ -158,32 +158,35 @@ def test_ref_sharded_knn_class_single_rank(tmp_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d", [8, 32])
-def test_sixteen_to_thirty_neighbours_on_pooled_lists_of_sixteen(N, d):
-    """k + self = 16 .. 30 on the second-generation pre-filter: lists of 16 per lane with thresholds of rank 22 / 27 / 31
-    over the two lists of a query kept as one pool (coarse2.hip.h, pair_union_rank).  About one query in forty has 16 or
-    more of its first 22 neighbours in one lane's half of the rows: those go through the hand-over between the lists.
-    8,000 reference rows (v2 needs 4,096), some duplicated (ties across the k-th slot), 6,000 query rows, X=None too."""
+@pytest.mark.parametrize("d", [8, 32, 64])
+def test_more_neighbours_than_a_list_holds_on_pooled_lists(N, d):
+    """k + self = 6 .. 7 on lists of 6, 8 .. 15 on lists of 8, 16 .. 31 on lists of 16 (second-generation pre-filter):
+    thresholds of a rank beyond one list over the two lists of a query kept as one pool (coarse2.hip.h, pair_union_rank,
+    coarse2_rank_extra).  A query with more of its neighbours in one lane's half of the rows than that lane's list holds
+    (about one in forty at 16 of 22) goes through the hand-over between the lists.  8,000 reference rows (v2 needs 4,096),
+    some duplicated (ties across the k-th slot), 6,000 query rows, X=None too.  64 features: lists of 6 only (four K-steps),
+    the others stay on the first-generation kernel."""
     from oracle import oracle as O
     from sknnr_amd import synth
 
     x_ref, y, x_q = synth.make_problem(8_000, 6_000, d, t=2, n_dup_refs=24, n_dup_queries=16)
     ix = N.Index(x_ref, y)
-    for k in (16, 20, 21, 25, 29, 30):
+    for k in (6, 7, 8, 10, 11, 13, 14, 15, 16, 20, 21, 25, 26, 30, 31):
         dist, idx = ix.kneighbors_host(x_q, ix.make_opts(k))
         od, oi = O.kneighbors(x_ref, x_q, k, "expanded")
-        np.testing.assert_array_equal(idx, oi)
-        np.testing.assert_array_equal(dist, od)
+        np.testing.assert_array_equal(idx, oi, err_msg=f"k={k}")
+        np.testing.assert_array_equal(dist, od, err_msg=f"k={k}")
         st = ix.stats()
         assert st["coarse_queries"] >= 6_000 and st["exact_only_queries"] == 0, st
-    for k in (15, 20, 29):  # + self: 16, 21, 30
+    for k in (6, 7, 10, 15, 20, 30):  # + self: 7, 8, 11, 16, 21, 31
         dist, idx = ix.kneighbors_host(None, ix.make_opts(k, exclude_self=True), nq=8_000)
         od, oi = O.kneighbors(x_ref, None, k, "expanded")
-        np.testing.assert_array_equal(idx, oi)
-        np.testing.assert_array_equal(dist, od)
+        np.testing.assert_array_equal(idx, oi, err_msg=f"k={k}")
+        np.testing.assert_array_equal(dist, od, err_msg=f"k={k}")
     # the certificate still carries most rows (no wholesale fall-back to the scan)
-    ix.reset_stats()
-    ix.kneighbors_host(x_q, ix.make_opts(20))
-    st = ix.stats()
-    assert st["exact_fallbacks"] <= 0.05 * 6_000, st
+    for k in (7, 10, 20):
+        ix.reset_stats()
+        ix.kneighbors_host(x_q, ix.make_opts(k))
+        st = ix.stats()
+        assert st["exact_fallbacks"] <= 0.05 * 6_000, (k, st)
     ix.close()
