@@ -16,7 +16,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libsknnr_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 SOURCES = ["sknnr_hip.hip"]
-HEADERS = ["coarse.hip.h", "coarse2.hip.h", "exact.hip.h", "../../include/sknnr_hip.h"]
+HEADERS = ["coarse.hip.h", "coarse2.hip.h", "bucket.hip.h", "hamming.hip.h", "exact.hip.h", "../../include/sknnr_hip.h"]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

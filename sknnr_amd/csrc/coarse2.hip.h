@@ -60,10 +60,16 @@ __host__ __device__ constexpr int seed_tiles_for(long n_tiles, int tps) {
     const long stages = want / tps < 1 ? 1 : want / tps;
     return (int)(stages * tps);
 }
+#ifndef SKNNR_V2_PAIR_FLUSH
+#define SKNNR_V2_PAIR_FLUSH 1  // the flush walks the entries of the two lanes of a query as one sequence, two per trip
+#endif
 constexpr int kCoarse2Waves = SKNNR_V2_WAVES;
 constexpr int kCoarse2Nqb = 2;
 constexpr int kQueueCap = 5;      // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
-constexpr int kQueueFlushAt = 3;  // a visit ends with a flush once some lane holds this many
+#ifndef SKNNR_V2_FLUSH_AT
+#define SKNNR_V2_FLUSH_AT 3
+#endif
+constexpr int kQueueFlushAt = SKNNR_V2_FLUSH_AT;  // a visit ends with a flush once some lane holds this many
 // per wave: the queues [q-block][entry][lane] 8-byte pairs, then the row behind every lane's column [q-block][lane] (4 bytes)
 __host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb * kQueueCap * 64 * 8 + kCoarse2Nqb * 64 * 4; }
 // measured against coarse_kernel on 4.19M x 50k rows (profiles/r02_v2_vs_v1.txt): 6-entry lists win for KS <= 4, 8-entry
@@ -348,6 +354,57 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         CTR(6, 1);
         unsigned long long any_aside = 0;  // (E > 0) lanes that set an entry aside for the partner's list
         int n_iter = 0;
+#if SKNNR_V2_PAIR_FLUSH && !defined(SKNNR_V2_NO_CORR) && !defined(SKNNR_V2_FLUSH_COMBINED)
+        constexpr bool PAIR_FLUSH = E == 0;
+#else
+        constexpr bool PAIR_FLUSH = false;
+#endif
+        if constexpr (PAIR_FLUSH) {
+            // The entries of the two lanes of a query (lower lane's first, then the upper lane's) are ONE sequence, taken
+            // two per trip: entry 2i is finished by the lower lane and goes to ITS list, entry 2i + 1 by the upper lane.
+            // A flush is triggered by one lane holding kQueueFlushAt entries while most hold none or one: the trips are
+            // ceil(most entries of a PAIR / 2) instead of the most entries of a LANE -- two instead of three as a rule.
+            // Which of the two lists holds an entry does not matter to the certificate (what a list of M drops is >= its
+            // last entry >= the M-th smallest of the union, whatever rows it was fed), and the corrected value is the
+            // same sum of the same two halves.
+            const int c_par = __shfl_xor(cnt[qb], 32, 64);
+            const int c_low = half ? c_par : cnt[qb];
+            const int total = cnt[qb] + c_par;
+            const unsigned q_low = half ? qlane - 256u : qlane;  // the lower lane's slots; the upper lane's are 256 bytes on
+            auto slot_of = [&](int n) { return n < c_low ? q_low + (unsigned)n * 512u : q_low + 256u + (unsigned)(n - c_low) * 512u; };
+            for (int i = 0; __builtin_amdgcn_ballot_w64(2 * i < total) != 0; ++i) {
+                CTR(7, 1);
+                CTR(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(2 * i + half < total)));
+                const bool on0 = 2 * i < total, on1 = 2 * i + 1 < total;
+                unsigned long long e0, e1;
+                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(e0), "=&v"(e1)
+                             : "v"(slot_of(on0 ? 2 * i : 0)), "v"(slot_of(on1 ? 2 * i + 1 : 0))
+                             : "memory");
+                const int pos_0 = on0 ? (int)(e0 >> 32) : 0, pos_1 = on1 ? (int)(e1 >> 32) : 0;
+                auto partial = [&](int pos) {  // this lane's K half of the two correction products of one entry
+                    const unsigned row = (unsigned)(pos & 31) * 16u + (unsigned)frag_off;
+                    const unsigned oh = (unsigned)(pos >> 5) * (unsigned)TB + row;
+                    const unsigned ol = (unsigned)(pos >> 5) * (unsigned)(KS * 1024) + row;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const half8 fl = *(const half8*)(rlo + ol + s * 1024);
+                        const half8 fh = *(const half8*)(rhi + oh + s * 1024);
+                        acc = dot8(fl, bh[qb][s], acc);
+                        acc = dot8(fh, bl[s], acc);
+                    }
+                    return acc;
+                };
+                const float part_0 = partial(pos_0);
+                __builtin_amdgcn_sched_barrier(0);
+                const float part_1 = partial(pos_1);
+                const float other = __shfl_xor(half ? part_0 : part_1, 32, 64);  // the partner's half of the entry I finish
+                const unsigned long long e_mine = half ? e1 : e0;
+                const float cv = __uint_as_float((unsigned)e_mine) + ((half ? part_1 : part_0) + other);
+                if ((half ? on1 : on0) && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, (int)(e_mine >> 32));
+            }
+        } else
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt[qb]) != 0; ++i) {
             CTR(7, 1);
             CTR(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < cnt[qb])));
