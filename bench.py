@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (skip configs 2-5, host paths, laws)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of (dist, idx)")
+    ap.add_argument("--gather-chunks", type=int, default=2, choices=[1, 2, 3, 4], help="N>1: calls a rank's share is split into (all but the last gather overlap compute)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (self-test of the N>1 path)")
     return ap.parse_args()
@@ -109,6 +110,19 @@ def fit_space(kind, n_ref, d_in, t, device, n_components=None, x_ref=None):
     eng = KNNEngine(x_ref_t, y, device=device)
     eng.set_affine(d_in, center, scale, proj)
     return eng, x_ref_t, (center, scale, proj), y, time.perf_counter() - t0
+
+
+def gather_cuts(nq, n_chunks):
+    """Row ranges of the calls one rank's share is split into (N > 1), cut at whole rounds of the pre-filter grid."""
+    round_rows = 256 * 1024
+    n_rounds = -(-nq // round_rows)
+    weights = {1: (), 2: (0.6,), 3: (0.45, 0.33), 4: (0.31, 0.28, 0.23)}[n_chunks]
+    cuts, acc_w = [0], 0.0
+    for w_ in weights:
+        acc_w += w_
+        cuts.append(min(nq, max(cuts[-1], int(round(acc_w * n_rounds)) * round_rows)))
+    cuts.append(nq)
+    return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
 def timed(fn, torch, steps=2, warmup=1):
@@ -327,6 +341,17 @@ def hamming_config(torch, nq=200_000, n_ref=20_000, n_trees=500, k=5, levels=300
 
 def main():
     args = parse_args()
+    # Libraries print to stdout (RCCL's version banner at communicator creation, for one): the contract is ONE JSON line
+    # there, so file descriptor 1 points at stderr until that line is written.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        print(line, flush=True)
+
     import torch
 
     rank = int(os.environ.get("RANK", 0))
@@ -358,17 +383,13 @@ def main():
     k = args.k
     q = gen_queries(nq, args.dims, 1000 + rank, torch)
 
-    # N > 1: four all-gather chunks (chunk i travels while chunk i+1 is computed), cut at whole rounds
-    # of the pre-filter grid (256 CUs x 1024 rows per workgroup) and shrinking, so that the last
-    # gather -- the only one nothing hides -- is the smallest
-    round_rows = 256 * 1024
-    n_rounds = -(-nq // round_rows)
-    cuts, acc_w = [0], 0.0
-    for w_ in (0.31, 0.28, 0.23):
-        acc_w += w_
-        cuts.append(min(nq, max(cuts[-1], int(round(acc_w * n_rounds)) * round_rows)))
-    cuts.append(nq)
-    gather_chunks = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    # N > 1: two all-gather chunks (the first travels while the second is computed), cut at a whole round of the
+    # pre-filter grid (256 CUs x 1024 rows per workgroup).  Every chunk is a call of its own: it drains the device at its
+    # end and pays the fixed part of the finaliser / exact scan again -- measured on one GPU with one rank's share of the job
+    # (scripts/rank_share_probe.sh, profiles/r03_rank_share.txt): four chunks cost +3.3 / +1.2 / +1.8 ms at N = 2 / 4 / 8
+    # against 25.6 / 14.0 / 6.8 ms for the share as one call, about what the gather they hide takes (800 MB x (N-1)/N per
+    # rank over xGMI).  Two chunks halve that and leave 40 % of the gather in the open.  (--gather-chunks)
+    gather_chunks = gather_cuts(nq, args.gather_chunks)
     comm_stream = torch.cuda.Stream() if use_dist else None
     gather_in_place = [True]
 
@@ -506,7 +527,7 @@ def main():
         if world == 1 and not args.no_extras and not use_dist:
             del d_out, i_out
             result.update(extras(args, eng, q, x_ref_t, affine, torch, local_rank))
-        print(json.dumps(result))
+        emit(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
 
@@ -523,8 +544,14 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
     for n_gpu in (2, 4, 8):
         share = nq // n_gpu
         wall, _ = timed(lambda: eng.kneighbors(q[:share], k, apply_affine=True, deterministic=True), torch, steps=3, warmup=1)
+        chunks = gather_cuts(share, args.gather_chunks)
+        wall_c, _ = timed(lambda: [eng.kneighbors(q[a:b], k, apply_affine=True, deterministic=True, row_offset=a) for a, b in chunks][-1],
+                          torch, steps=3, warmup=1)
         pred[str(n_gpu)] = {"rows_per_gpu": share, "ms_per_share": wall * 1e3, "predicted_Mq_s_before_gather": nq / wall / 1e6,
-                            "gather_bytes_received_per_rank": (n_gpu - 1) * share * k * 16}
+                            "ms_per_share_in_gather_chunks": wall_c * 1e3, "gather_chunks": len(chunks),
+                            "predicted_Mq_s_chunked_before_last_gather": nq / wall_c / 1e6,
+                            "gather_bytes_received_per_rank": (n_gpu - 1) * share * k * 16,
+                            "last_gather_bytes_received_per_rank": (n_gpu - 1) * (chunks[-1][1] - chunks[-1][0]) * k * 16}
     out["strong_scaling_expectation"] = pred
 
     # ---- the headline workload entered from host arrays (PCIe-inclusive; never `value`) ----------

@@ -1323,15 +1323,18 @@ int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStrea
 // last round of a launch leaves most CUs idle when it holds few workgroups (10M rows: 9768 workgroups =
 // 38 rounds + 40), and a small call never fills the device.  Rows of such a thin round (at most a quarter of
 // the CUs' worth) go to 4-wave workgroups instead: four times as many CUs, one wave per SIMD.
+// `rows`: the live rows of the chunk -- its padding rows (up to kRowQuantum - 1 of them, behind the live ones also in a
+// bucketed call) get no workgroups of their own: a 262,144-row call is 256 workgroups, not 258 with a thin round of two.
 template <int KS, int M>
-int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
+int launch_coarse2_ks(sknnr_index* ix, long rows, int kk, hipStream_t st) {
     constexpr int BULK_WAVES = coarse2_waves(KS, M);
     constexpr long QPB = BULK_WAVES * kCoarse2Nqb * 32;
+    constexpr long QPB_TAIL = kCoarse2TailWaves * kCoarse2Nqb * 32;
     static const bool split = [] {
         const char* e = std::getenv("SKNNR_COARSE_TAIL");
         return !(e && std::atoi(e) == 0);
     }();
-    const long n_wg = nq_pad / QPB;
+    const long n_wg = (rows + QPB - 1) / QPB;
     long tail_wg = n_wg % kCusPerDevice;
     if (!split || tail_wg > kCusPerDevice / (BULK_WAVES / kCoarse2TailWaves)) tail_wg = 0;
     const long bulk_rows = (n_wg - tail_wg) * QPB;
@@ -1348,7 +1351,10 @@ int launch_coarse2_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
             ix->bulk_rows_done = bulk_rows;
         }
     }
-    if (tail_wg > 0) return launch_coarse2_waves<KS, M, kCoarse2TailWaves>(ix, bulk_rows, tail_wg * QPB, kk, st);
+    if (tail_wg > 0) {
+        const long tail_rows = std::min(tail_wg * QPB, (rows - bulk_rows + QPB_TAIL - 1) / QPB_TAIL * QPB_TAIL);
+        return launch_coarse2_waves<KS, M, kCoarse2TailWaves>(ix, bulk_rows, tail_rows, kk, st);
+    }
     return SKNNR_OK;
 }
 
@@ -1365,7 +1371,7 @@ bool use_coarse2(const sknnr_index* ix, int m_list) {
     return enabled && tiles2 >= 2 * kSeedTiles && tiles2 * tile2_bytes(ix->ks) < (1L << 32) && coarse2_supported(ix->ks, m_list);
 }
 
-int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
+int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {  // (nq_pad: the live rows, see launch_coarse2_ks)
     if (ix->ks == 1 && m_list == 2) return launch_coarse2_ks<1, 2>(ix, nq_pad, kk, st);
     if (ix->ks == 2 && m_list == 2) return launch_coarse2_ks<2, 2>(ix, nq_pad, kk, st);
     if (ix->ks == 1 && m_list == 6) return launch_coarse2_ks<1, 6>(ix, nq_pad, kk, st);
@@ -1699,7 +1705,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
                                   : (long)ix->n_stages * tiles_per_stage(ix->ks);
             ix->stats.mfma_executed_ratio = (double)tiles * 32.0 * (16.0 * ix->ks) / ((double)ix->n_ref * ix->d);
         }
-        int rc = v2 ? launch_coarse2(ix, n_pad, coarse_list_len(ix, kk), kk, st)
+        int rc = v2 ? launch_coarse2(ix, n, coarse_list_len(ix, kk), kk, st)
                     : launch_coarse(ix, n_pad, coarse_list_len(ix, kk), kk, st);
         if (rc) return rc;
         if (ix->ev_bulk_end) HIP_TRY(hipEventRecord(ev.second, st));  // (no fork: the whole pre-filter is timed)
