@@ -183,3 +183,23 @@ def test_synthetic_generators_are_deterministic():
     np.testing.assert_array_equal(a, b)
     x, y, q = synth.make_problem(200, 50, 8, t=5, kind="positive", n_dup_refs=10, n_dup_queries=5)
     assert (y > 0).all() and np.array_equal(x[-10:], x[:10]) and np.array_equal(q[0], x[0])
+
+
+def test_bench_gather_cuts_cover_the_share_in_whole_rounds():
+    """bench.py, N > 1: the calls a rank's share is split into are contiguous, cover it exactly, and every cut but the last
+    falls on a whole round of the pre-filter grid (256 workgroups x 1024 rows)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for nq in (1, 100, 262_144, 1_250_000, 2_500_000, 5_000_000, 10_000_000):
+        for n_chunks in (1, 2, 3, 4):
+            cuts = bench.gather_cuts(nq, n_chunks)
+            assert cuts[0][0] == 0 and cuts[-1][1] == nq and 1 <= len(cuts) <= n_chunks
+            for (a, b), (c, d) in zip(cuts[:-1], cuts[1:]):
+                assert b == c and a < b
+            for a, b in cuts[:-1]:
+                assert b % (256 * 1024) == 0
+    assert bench.gather_cuts(1_250_000, 2) == [(0, 786_432), (786_432, 1_250_000)]
