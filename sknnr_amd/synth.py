@@ -70,3 +70,29 @@ def make_problem(
         x_q[:n_dup_queries] = x_ref[::step][:n_dup_queries]
     y = make_targets(x_ref, t=t, kind=kind)
     return x_ref, y, x_q
+
+
+def make_forest_ids(n_ref: int, nq: int, n_trees: int, d: int = 6, cuts: int = 7, seed: int = 0, query_noise: float = 0.15):
+    """Node ids shaped like a forest's ``apply`` output, without growing one: points in ``d`` dimensions (queries are
+    jittered copies of reference points), and per tree an axis-aligned partition of a random 3-D subspace into
+    ``cuts``^3 cells at jittered quantiles -- rows that are close share the cell in most trees, rows that are not share it
+    in about 1 / cuts^3 of them.  Returns float64 ``(ref_ids, query_ids)`` of shape ``(n, n_trees)``, ids < cuts^3."""
+    rng = np.random.default_rng(seed)
+    x_ref = rng.standard_normal((n_ref, d))
+    src = rng.integers(0, n_ref, nq)
+    x_q = x_ref[src] + query_noise * rng.standard_normal((nq, d))
+    ref_ids = np.empty((n_ref, n_trees), dtype=np.float64)
+    q_ids = np.empty((nq, n_trees), dtype=np.float64)
+    base = np.linspace(0.0, 1.0, cuts + 1)[1:-1]
+    for t in range(n_trees):
+        feats = rng.choice(d, size=3, replace=False)
+        rid = np.zeros(n_ref, dtype=np.int64)
+        qid = np.zeros(nq, dtype=np.int64)
+        for f in feats:
+            edges = np.quantile(x_ref[:, f], np.clip(base + rng.uniform(-0.4, 0.4, cuts - 1) / cuts, 0.01, 0.99))
+            edges.sort()
+            rid = rid * cuts + np.searchsorted(edges, x_ref[:, f])
+            qid = qid * cuts + np.searchsorted(edges, x_q[:, f])
+        ref_ids[:, t] = rid
+        q_ids[:, t] = qid
+    return ref_ids, q_ids
