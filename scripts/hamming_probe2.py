@@ -42,5 +42,5 @@ for mode in ("0", "1"):
     ok = bool(np.array_equal(di[:n_chk].cpu().numpy(), oi) and np.array_equal(dd[:n_chk].cpu().numpy(), od))
     print(f"{'integer pre-filter' if mode == '1' else 'float64 scan      '}: {n_ref} refs x {nq} queries x {t} trees, k={k}, {levels} ids/tree, "
           f"{'uniform' if uniform else 'real'} weights: {ms:8.2f} ms = {n_ref * nq * t / ms / 1e9:8.2f} e12 compares/s, {nq / ms / 1e3:.3f} Mq/s; "
-          f"oracle slice ({n_chk} rows) bit-equal: {ok}", flush=True)
+          f"fallbacks {st['exact_fallbacks']}; oracle slice ({n_chk} rows) bit-equal: {ok}", flush=True)
     ix.close()

@@ -69,6 +69,37 @@ __device__ __forceinline__ void ham_step(unsigned& acc, uint32_t r, uint32_t q, 
         : [r] "v"(r), [q] "v"(q), [w] "v"(w), [ones] "v"(ones));
 }
 
+// The same four steps with the queries' ids and the weight pair in SCALAR registers (one constant-bus operand per
+// instruction): they are workgroup-uniform, a scalar load fetches the sixteen ids of a tree pair in one instruction, and the
+// 64 vector registers that held them (four tree pairs in flight) are what kept the kernel at four waves per SIMD -- too few
+// to cover the loads it waits for at the top of every trip (0.55 of the instruction roofline, profiles/r03_bench_output.json).
+#ifndef SKNNR_HAM_SGPR
+#define SKNNR_HAM_SGPR 1
+#endif
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void ham_step4s(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, uint32_t r, uint32_t q0, uint32_t q1,
+                                           uint32_t q2, uint32_t q3, uint32_t w, uint32_t ones) {
+    uint32_t t0, t1, t2, t3;
+    asm volatile("v_xor_b32 %[t0], %[q0], %[r]\n\t"  // (volatile: stays behind the s_waitcnt that covers its scalar operands)
+        "v_xor_b32 %[t1], %[q1], %[r]\n\t"
+        "v_xor_b32 %[t2], %[q2], %[r]\n\t"
+        "v_xor_b32 %[t3], %[q3], %[r]\n\t"
+        "v_pk_min_u16 %[t0], %[t0], %[ones]\n\t"
+        "v_pk_min_u16 %[t1], %[t1], %[ones]\n\t"
+        "v_pk_min_u16 %[t2], %[t2], %[ones]\n\t"
+        "v_pk_min_u16 %[t3], %[t3], %[ones]\n\t"
+        "v_dot2_u32_u16 %[a0], %[t0], %[w], %[a0]\n\t"
+        "v_dot2_u32_u16 %[a1], %[t1], %[w], %[a1]\n\t"
+        "v_dot2_u32_u16 %[a2], %[t2], %[w], %[a2]\n\t"
+        "v_dot2_u32_u16 %[a3], %[t3], %[w], %[a3]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [r] "v"(r), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [w] "s"(w), [ones] "v"(ones));
+}
+// sixteen consecutive dwords (64-byte aligned) and one dword through the scalar cache
+__device__ __forceinline__ void ham_sload(u32x16& q, uint32_t& w, const uint32_t* qp, const uint32_t* wp) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0" : "=&s"(q), "=&s"(w) : "s"(qp), "s"(wp) : "memory");
+}
+
 struct HammingArgs {
     const uint32_t* rimg;   // [tp][n_ref_pad] two 16-bit ids per dword
     const uint32_t* wq;     // [tp] two 16-bit weights per dword
@@ -125,6 +156,32 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
 #pragma unroll
         for (int j = 0; j < kHamNq; ++j) acc[j] = 0;
         int p = 0;
+#if SKNNR_HAM_SGPR
+        for (; p + 4 <= a.tp; p += 4) {
+            // four tree pairs per trip: the reference dwords by vector loads, then per tree pair one scalar load of the sixteen
+            // queries' ids (and the weight pair) and 48 instructions of arithmetic; the next pair's scalar load is in flight
+            // meanwhile
+            uint32_t rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rv[u] = rcol[(size_t)(p + u) * a.n_ref_pad];
+            u32x16 qs[2];
+            uint32_t ws[2];
+            ham_sload(qs[0], ws[0], qbase + (size_t)p * a.nq_pad, a.wq + p);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // (scalar loads return out of order: the only wait is for all of them -- so the next pair's load goes out
+                //  once this pair's has landed, and travels during this pair's arithmetic)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (u + 1 < 4) ham_sload(qs[(u + 1) & 1], ws[(u + 1) & 1], qbase + (size_t)(p + u + 1) * a.nq_pad, a.wq + p + u + 1);
+                const u32x16& q = qs[u & 1];
+                const uint32_t w = ws[u & 1];
+                ham_step4s(acc[0], acc[1], acc[2], acc[3], rv[u], q[0], q[1], q[2], q[3], w, ones);
+                ham_step4s(acc[4], acc[5], acc[6], acc[7], rv[u], q[4], q[5], q[6], q[7], w, ones);
+                ham_step4s(acc[8], acc[9], acc[10], acc[11], rv[u], q[8], q[9], q[10], q[11], w, ones);
+                ham_step4s(acc[12], acc[13], acc[14], acc[15], rv[u], q[12], q[13], q[14], q[15], w, ones);
+            }
+        }
+#else
         for (; p + 4 <= a.tp; p += 4) {
             // four tree pairs per trip: the reference dwords, the weights and the sixteen queries' ids (workgroup-uniform
             // 64-byte rows) of all four are requested together, then 192 instructions of arithmetic
@@ -146,6 +203,7 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
                               qv[u][g].w, wv[u], ones);
             }
         }
+#endif
         for (; p < a.tp; ++p) {
             const uint32_t rvv = rcol[(size_t)p * a.n_ref_pad];
             const uint32_t w = a.wq[p];
