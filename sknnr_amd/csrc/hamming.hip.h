@@ -275,17 +275,51 @@ struct HammingRescoreArgs {
     int* fail_list;         // queries for exact_scan_kernel<2> (overflow, bad ids)
     int* fail_count;
     int fail_base;
+    const uint32_t* rrow;   // [n_ref][tpr] row-major 16-bit ids of the references (hamming_rows_kernel)
+    int tpr;
 };
 
-// One wave per query: every lane re-scores candidates in the reference's float64 arithmetic (the same expression, in
-// tree order, as exact_scan_kernel<2>), lane 0 selects by (distance, index) in ascending index order and finishes.
+// Row-major copy of the references' 16-bit ids for the re-score: [row][tpr] dwords (two ids each), tpr a multiple of 256
+// (one KiB per 512 trees), zeros past the last tree.
+__host__ __device__ constexpr int ham_row_dwords(int t) { return (t + 511) / 512 * 256; }
+__global__ void __launch_bounds__(256) hamming_rows_kernel(const double* __restrict__ x, long n, int t, int tpr, uint32_t* __restrict__ rows) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one dword per thread
+    if (i >= n * tpr) return;
+    const long row = i / tpr;
+    const int p = (int)(i - row * tpr);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int c = 2 * p + hh;
+        const double v = c < t ? x[row * t + c] : 0.0;
+        packed |= ((v >= 0.0 && v <= 65535.0) ? (uint32_t)v : 0u) << (16 * hh);
+    }
+    rows[i] = packed;
+}
+
+// One wave per query.  The candidates' distances in the reference's float64 arithmetic -- s += w_t for every tree whose ids
+// differ, IN TREE ORDER -- then lane 0 selects by (distance, index) in ascending index order and finishes, exactly as
+// exact_scan_kernel<2> does over all rows.
+//   phase 1, per candidate, all lanes: which trees differ?  Lane l compares trees 512 c + 8 l .. + 7 of chunk c on the 16-bit
+//            ids (equal as float64 iff equal as integers: both sides were validated), one coalesced KiB of the row-major
+//            image per chunk, and leaves one byte of flags in LDS;
+//   phase 2, lane i = candidate i of the batch of 64: the weights of the flagged trees are summed in tree order (flags and
+//            weights from LDS: no memory traffic, the float64 additions are the same chain the reference runs).
+// (Until round 3 every lane walked its own candidate's float64 row, 8 bytes per load out of 64 different rows: 19.3 ms of
+//  the 105 ms of the 200k x 20k x 500 benchmark call.)
 __global__ void __launch_bounds__(256) hamming_rescore_kernel(HammingRescoreArgs a) {
     __shared__ double dv[4][kHamCand];
     __shared__ double hv[4][kHamMaxKK + 2];
     __shared__ int hi[4][kHamMaxKK + 2];
     __shared__ int stack[4][2 * kHamMaxKK + 8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];  // [T] float64 weights, then per wave [64][chunks * 64] flag bytes
     const SelectArgs& s = a.s;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int T = s.d, chunks = (T + 511) / 512, fb = chunks * 64;  // flag bytes per candidate
+    double* hw_l = (double*)rs_lds;
+    unsigned char* flags = rs_lds + (size_t)((T + 1) / 2 * 2) * 8 + (size_t)wave * 64 * fb;
+    for (int t = threadIdx.x; t < T; t += 256) hw_l[t] = s.hw[t];
+    __syncthreads();
     const long q = (long)blockIdx.x * 4 + wave;
     if (q >= s.nq) return;
     const int c = a.cand_cnt[q];
@@ -296,14 +330,53 @@ __global__ void __launch_bounds__(256) hamming_rescore_kernel(HammingRescoreArgs
         }
         return;
     }
-    const double* x = s.xq + q * s.d;
-    for (int i = lane; i < c; i += 64) {
-        const double* r = s.ref + (long)a.cand_id[q * kHamCand + i] * s.d;
-        double acc = 0.0;
-        for (int t = 0; t < s.d; ++t) acc = x[t] != r[t] ? acc + s.hw[t] : acc;
-        dv[wave][i] = acc / s.hw_sum;
+    // this lane's eight trees of every chunk of the query, as four dwords of 16-bit ids
+    constexpr int kMaxChunks = 8;  // 4,096 trees
+    uint4 qv[kMaxChunks];
+    const double* x = s.xq + q * T;
+#pragma unroll
+    for (int k = 0; k < kMaxChunks; ++k) {
+        uint32_t w4[4] = {0, 0, 0, 0};
+        if (k < chunks) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = 512 * k + 8 * lane + i;
+                const uint32_t id = t < T ? (uint32_t)x[t] : 0u;
+                w4[i >> 1] |= id << (16 * (i & 1));
+            }
+        }
+        qv[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
-    __builtin_amdgcn_wave_barrier();
+    for (int b0 = 0; b0 < c; b0 += 64) {
+        const int nb = min(64, c - b0);
+        for (int i = 0; i < nb; ++i) {  // phase 1
+            const uint32_t* row = a.rrow + (size_t)a.cand_id[q * kHamCand + b0 + i] * a.tpr;
+#pragma unroll
+            for (int k = 0; k < kMaxChunks; ++k) {
+                if (k >= chunks) break;
+                const uint4 rv = *(const uint4*)(row + 256 * k + 4 * lane);
+                const uint32_t d0 = rv.x ^ qv[k].x, d1 = rv.y ^ qv[k].y, d2 = rv.z ^ qv[k].z, d3 = rv.w ^ qv[k].w;
+                const uint32_t f = ((d0 & 0xffffu) ? 1u : 0u) | ((d0 >> 16) ? 2u : 0u) | ((d1 & 0xffffu) ? 4u : 0u) | ((d1 >> 16) ? 8u : 0u) |
+                                   ((d2 & 0xffffu) ? 16u : 0u) | ((d2 >> 16) ? 32u : 0u) | ((d3 & 0xffffu) ? 64u : 0u) | ((d3 >> 16) ? 128u : 0u);
+                flags[(size_t)i * fb + 64 * k + lane] = (unsigned char)f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < nb) {  // phase 2
+            const unsigned char* fl = flags + (size_t)lane * fb;
+            double acc = 0.0;
+            for (int t8 = 0; t8 * 8 < T; ++t8) {
+                const unsigned f = fl[t8];
+                const int t0 = 8 * t8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (t0 + i < T) acc = (f >> i) & 1u ? acc + hw_l[t0 + i] : acc;
+            }
+            dv[wave][b0 + lane] = acc / s.hw_sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0) {
         const int KK = s.kk;
@@ -318,5 +391,6 @@ __global__ void __launch_bounds__(256) hamming_rescore_kernel(HammingRescoreArgs
         scan_finish_query<2>(s, q, hv[wave], hi[wave], stack[wave]);
     }
 }
+__host__ inline size_t hamming_rescore_lds(int t) { return (size_t)((t + 1) / 2 * 2) * 8 + (size_t)4 * 64 * ((t + 511) / 512 * 64); }
 
 }  // namespace sknnr

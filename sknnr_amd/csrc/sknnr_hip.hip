@@ -245,7 +245,7 @@ struct sknnr_index {
     // integer pre-filter of the weighted-Hamming search (hamming.hip.h): 16-bit ids / weights, two trees per dword
     bool h16_ok = false;           // every reference id is an integer in [0, 65535]
     int h_tp = 0, h_ref_pad = 0;   // tree pairs; reference rows padded to the step of the kernel
-    DevBuf<uint32_t> h_rimg, h_wq, h_qimg;
+    DevBuf<uint32_t> h_rimg, h_wq, h_qimg, h_rrow;  // (h_rrow: row-major ids for the re-score)
     DevBuf<int> h_bad, h_cand_cnt, h_cand_id;
     DevBuf<double> ref64, refT, rn64, y64, mu_dev;  // refT: (d, n_ref) transposed copy for the exact scan
     DevBuf<char> rimg;
@@ -323,7 +323,7 @@ struct sknnr_index {
         perm2.release();
         cell_axes.release(); cell_centre.release(); cell_thr.release(); cell_stage.release();
         qcell.release(); qperm.release(); cell_hist.release(); qlo.release();
-        h_rimg.release(); h_wq.release(); h_qimg.release(); h_bad.release(); h_cand_cnt.release(); h_cand_id.release();
+        h_rimg.release(); h_wq.release(); h_qimg.release(); h_rrow.release(); h_bad.release(); h_cand_cnt.release(); h_cand_id.release();
         qimg.release();
         cand_val.release();
         cand_idx.release();
@@ -1015,9 +1015,18 @@ extern "C" int sknnr_index_set_hamming_weights(sknnr_index* ix, const double* w,
         HIP_TRY(hipMemcpy(hb.data(), bad.p, (size_t)ref_pad * sizeof(int), hipMemcpyDeviceToHost));
         bool any_bad = false;
         for (int v : hb) any_bad = any_bad || v != 0;
+        const int tpr = ham_row_dwords(n);
+        bool rows_ok = n <= 4096 && hamming_rescore_lds(n) <= 150 * 1024;
+        if (rows_ok) {
+            HIP_TRY(ix->h_rrow.ensure((size_t)ix->n_ref * tpr));
+            const long n_dw = (long)ix->n_ref * tpr;
+            hamming_rows_kernel<<<dim3((unsigned)((n_dw + 255) / 256)), dim3(256)>>>(ix->ref64.p, ix->n_ref, n, tpr, ix->h_rrow.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
         ix->h_tp = tp;
         ix->h_ref_pad = ref_pad;
-        ix->h16_ok = !any_bad;
+        ix->h16_ok = !any_bad && rows_ok;  // (more than 4,096 trees: the float64 scan)
     }
     return SKNNR_OK;
 }
@@ -1817,7 +1826,11 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             hr.fail_list = ix->fail_list.p;
             hr.fail_count = ix->fail_count.p;
             hr.fail_base = (int)c0;
-            hamming_rescore_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st>>>(hr);
+            hr.rrow = ix->h_rrow.p;
+            hr.tpr = ham_row_dwords(ix->d);
+            const size_t rs_sh = hamming_rescore_lds(ix->d);
+            HIP_TRY(hipFuncSetAttribute((const void*)hamming_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_sh));
+            hamming_rescore_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), rs_sh, st>>>(hr);
             HIP_TRY(hipGetLastError());
         }
     }
