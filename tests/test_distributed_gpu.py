@@ -115,11 +115,11 @@ def test_bench_force_dist_single_rank():
     kernel timings) with one rank -- runs on the 1-GPU box."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1", "--rows", "3000000",
-           "--cpu-sample", "20000", "--no-extras"]
+           "--cpu-sample", "20000", "--no-extras", "--gather-chunks", "3"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["gather_in_place"] is True
-    assert res["roofline"]["timed_calls"] == 2 * 4  # four gather chunks per step, all summed
+    assert res["roofline"]["timed_calls"] == 2 * 3  # three gather chunks per step (--gather-chunks; default two), all summed
     assert 0 < res["roofline"]["frac"] <= 1.0
     assert res["parity_vs_cpu_reference"]["index_rows_equal"] == res["parity_vs_cpu_reference"]["rows"]
