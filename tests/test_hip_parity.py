@@ -140,7 +140,8 @@ def test_integer_features_many_exact_ties(N, O, deterministic, k):
 
 @pytest.mark.parametrize("k", [9, 14, 16, 30, 31, 40])
 def test_larger_k(N, O, k):
-    """k + self <= 31 stays on the MFMA path (lists of 16 / 32 per lane); beyond that the whole
+    """k + self <= 31 stays on the MFMA path (first-generation kernel here: 700 reference rows; lists of 16 / 32 per
+    lane -- the pooled lists of the second generation are covered by tests/test_round3_gpu.py); beyond that the whole
     call is answered by the exact scan."""
     x_ref, y, x_q = _synth(700, 300, 20)
     ix = N.Index(x_ref, y)
