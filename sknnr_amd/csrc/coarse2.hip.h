@@ -1,5 +1,5 @@
-// coarse2.hip.h -- second-generation MFMA pre-filter for feature spaces up to 64 wide (KS <= 4, lists of 6 / 8:
-// n_neighbors 2 .. 7 searched; coarse2_supported).
+// coarse2.hip.h -- second-generation MFMA pre-filter for feature spaces up to 64 wide (KS <= 4): lists of 2 / 6 / 8 / 16
+// per lane (coarse2_supported), 1 .. 31 neighbours searched (more than a list holds: pooled lists, pair_union_rank below).
 //
 // Same contract as coarse_kernel (coarse.hip.h): for every query, the M smallest ranking values
 //   v(q, r) ~= |r'|^2 - 2 q'.r'   seen by each of the two lanes that own the query, with the J-th
@@ -29,6 +29,13 @@
 //     q-block in the first tiles.
 //   * WAVES = 16 for the bulk of a call, 4 for the rows of a thin last round and for small calls (host side:
 //     launch_coarse2_ks).
+// Round 3 (DESIGN.md sections 4.1, 4.2; profiles/r03_*):
+//   * the image is in CELL order and the rows of a call are bucketed by cell (bucket.hip.h): a workgroup works on positions,
+//     starts its sweep (and takes its seeds) at the stage its middle row's cell names, and reads the queries' lo fragments
+//     from a position-ordered copy it makes at its start (qlo);
+//   * the flush walks the entries of a query's two lanes as ONE sequence, two per trip (SKNNR_V2_PAIR_FLUSH);
+//   * thresholds of a rank beyond one list over the two lists of a query kept as one pool (template parameter E):
+//     6 .. 31 neighbours on lists of 6 / 8 / 16.
 #pragma once
 #include "coarse.hip.h"
 
