@@ -190,3 +190,29 @@ def test_more_neighbours_than_a_list_holds_on_pooled_lists(N, d):
         st = ix.stats()
         assert st["exact_fallbacks"] <= 0.05 * 6_000, (k, st)
     ix.close()
+
+
+@pytest.mark.parametrize("trees", [37, 512, 600, 1100])
+def test_hamming_rescore_over_several_chunks_of_trees(N, trees):
+    """The weighted-Hamming re-score flags differing trees 512 at a time (hamming.hip.h): one, two and three chunks, a
+    tree count that is not a multiple of 8, few distinct ids (ties at the k-th distance are the norm), real-valued and
+    equal weights; X=None too.  Bit-equal to the oracle's float64 arithmetic."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(trees)
+    ref = rng.integers(0, 6, (1500, trees)).astype(np.float64)
+    src = rng.integers(0, 1500, 700)
+    q = np.where(rng.random((700, trees)) < 0.7, ref[src], rng.integers(0, 6, (700, trees)).astype(np.float64))
+    ix = N.Index(ref)
+    for w in (rng.random(trees) + 0.01, np.full(trees, 1.0 / trees)):
+        ix.set_hamming_weights(w)
+        for k in (1, 5, 12):
+            dist, idx = ix.kneighbors_host(q, ix.make_opts(k, formula=N.FORMULA_HAMMING))
+            od, oi = O.kneighbors_hamming(ref, q, w, k)
+            np.testing.assert_array_equal(idx, oi)
+            np.testing.assert_array_equal(dist, od)
+        dist, idx = ix.kneighbors_host(None, ix.make_opts(4, formula=N.FORMULA_HAMMING, exclude_self=True), nq=1500)
+        od, oi = O.kneighbors_hamming(ref, None, w, 4)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(dist, od)
+    ix.close()
