@@ -111,9 +111,10 @@ __device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc)
 //     max(a_{E-1}, b_{E-1}, max_{i = E .. M-1} min(a_i, b_{M+E-1-i}))
 // (k-th smallest of a union = max over i + j = k - 1 of min(a_i, b_j), entries past the end of a list counting as +inf).
 // Both lanes get the same value.  For this to bound what the LISTS let go of as well as what the skip test rejects, the
-// two lists of a query are kept as one pool of 2 M entries (flush: what one list displaces is offered to the other unless
-// it is already above the threshold), so that everything dropped is >= the final threshold or >= the larger of the two
-// last entries, which no rank of the union exceeds.
+// two lists of a query are kept as one pool of 2 M entries (flush: what one list lets go of -- the entry an insertion
+// displaces, or a candidate it does not take -- is handed to the other list at once unless it is already above the
+// threshold), so that everything dropped is >= the final threshold or has M entries below it in BOTH lists: >= the 2M-th
+// smallest of the pool, which no rank of the union exceeds.
 template <int M, int E>
 __device__ __forceinline__ float pair_union_rank(const float (&vals)[M]) {
     if constexpr (E == 0) {
@@ -359,10 +360,8 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #endif
         }
         CTR(6, 1);
-        unsigned long long any_aside = 0;  // (E > 0) lanes that set an entry aside for the partner's list
-        int n_iter = 0;
 #if SKNNR_V2_PAIR_FLUSH && !defined(SKNNR_V2_NO_CORR) && !defined(SKNNR_V2_FLUSH_COMBINED)
-        constexpr bool PAIR_FLUSH = E == 0;
+        constexpr bool PAIR_FLUSH = true;
 #else
         constexpr bool PAIR_FLUSH = false;
 #endif
@@ -409,7 +408,32 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
                 const float other = __shfl_xor(half ? part_0 : part_1, 32, 64);  // the partner's half of the entry I finish
                 const unsigned long long e_mine = half ? e1 : e0;
                 const float cv = __uint_as_float((unsigned)e_mine) + ((half ? part_1 : part_0) + other);
-                if ((half ? on1 : on0) && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, (int)(e_mine >> 32));
+                const bool on = half ? on1 : on0;
+                if constexpr (E == 0) {
+                    if (on && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, (int)(e_mine >> 32));
+                } else {
+                    // pooled lists (pair_union_rank): what this list lets go of is handed to the partner's at once, unless
+                    // it is no smaller than `loose` (which stays above the query's final threshold) -- rare once both lists
+                    // are full, and then one ballot
+                    float out_v = FLT_MAX;
+                    int out_i = -1;
+                    if (on) {
+                        if (cv < vals[qb][M - 1]) {
+                            out_v = vals[qb][M - 1];
+                            out_i = idxs[qb][M - 1];
+                            list_insert<M>(vals[qb], idxs[qb], cv, (int)(e_mine >> 32));
+                        } else {
+                            out_v = cv;
+                            out_i = (int)(e_mine >> 32);
+                        }
+                    }
+                    const bool offer = out_v < loose[qb];
+                    if (__builtin_amdgcn_ballot_w64(offer) != 0) {
+                        const float in_v = __shfl_xor(offer ? out_v : FLT_MAX, 32, 64);
+                        const int in_i = __shfl_xor(out_i, 32, 64);
+                        if (in_v < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], in_v, in_i);
+                    }
+                }
             }
         } else
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt[qb]) != 0; ++i) {
@@ -471,49 +495,8 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #endif
             const float from_partner = __shfl_xor(part_par, 32, 64);  // the partner's half of MY entry
             const float cv = ev + (part_own + from_partner);
-            if constexpr (E == 0) {
-                if (active && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, pos_own);
-            } else {
-                // One pool of 2 M entries per query: what this lane's list lets go of -- the entry an insertion displaces,
-                // or the candidate itself -- is set aside for the partner's list (in the queue slot this trip has
-                // read), unless it is no smaller than `loose`, which stays above the final threshold of the
-                // query (every later `tight` is at most this one, and loose >= tight): such an entry may go for good.
-                // (Lists that are not full let go of FLT_MAX.)
-                float out_v = FLT_MAX;
-                int out_i = -1;
-                if (active) {
-                    if (cv < vals[qb][M - 1]) {
-                        out_v = vals[qb][M - 1];
-                        out_i = idxs[qb][M - 1];
-                        list_insert<M>(vals[qb], idxs[qb], cv, pos_own);
-                    } else {
-                        out_v = cv;
-                        out_i = pos_own;
-                    }
-                }
-                // (every lane writes the slot it has just read, FLT_MAX when it has nothing to pass on: no per-lane
-                //  count to keep alive across the sweep)
-                const bool offer = out_v < loose[qb];
-                any_aside |= __builtin_amdgcn_ballot_w64(offer);
-                queue_store(qlane + i * 512, offer ? out_v : FLT_MAX, out_i);
-                n_iter = i + 1;
-            }
-        }
-        if constexpr (E > 0) {
-            // ... and every lane takes what its partner set aside.  In the steady state the last entry of a list lies
-            // above the rank the threshold is taken at, nothing is set aside and this is one scalar test.  What is
-            // dropped HERE has sixteen entries below it in both lists: it is >= the 32nd smallest of the pool, which no
-            // rank of the union exceeds.
-            if (any_aside != 0) {
-                const unsigned qpartner = half ? qlane - 256u : qlane + 256u;
-                for (int j = 0; j < n_iter; ++j) {
-                    const unsigned long long e = queue_load(qpartner + j * 512);
-                    const float in_v = __uint_as_float((unsigned)e);
-                    if (__builtin_amdgcn_ballot_w64(in_v < vals[qb][M - 1]) != 0) {
-                        if (in_v < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], in_v, (int)(e >> 32));
-                    }
-                }
-            }
+            static_assert(E == 0 || PAIR_FLUSH, "pooled lists hand entries over inside the pair flush");
+            if (active && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, pos_own);
         }
         cnt[qb] = 0;
         const float tight = pair_union_rank<M, E>(vals[qb]) + margin[qb];
