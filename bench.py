@@ -268,9 +268,16 @@ def extra_config(name, kind, nq, n_ref, d_in, k, torch, device, *, t=40, n_compo
     for _ in range(4 if small else 1):
         run()
     torch.cuda.synchronize()
-    eng.reset_stats()
-    wall, out = timed(run, torch, steps=6 if small else 2, warmup=0)
-    st = eng.stats()
+    # The MEDIAN pass (by wall time) is reported, with the kernel timings of that pass: the boxes of the pool show the odd
+    # pass 30-40 % slower than its neighbours (C5 25.3 / 36.6 ms on consecutive runs of one build), and a mean of two
+    # passes would carry it.
+    passes = []
+    for _ in range(7 if small else 3):
+        eng.reset_stats()
+        wall, out = timed(run, torch, steps=1, warmup=0)
+        passes.append((wall, eng.stats()))
+    passes.sort(key=lambda p: p[0])
+    wall, st = passes[len(passes) // 2]
     coarse_ms = st["total_coarse_ms"] / max(1, st["timed_calls"])
     kernel_ms = st["total_kernel_ms"] / max(1, st["timed_calls"])
     # (rows the timed pre-filter launches processed: the thin last round that runs beside the finaliser is not timed)
@@ -289,7 +296,7 @@ def extra_config(name, kind, nq, n_ref, d_in, k, torch, device, *, t=40, n_compo
     res = {"workload": name, "Mq_s": nq / wall / 1e6, "ms": wall * 1e3, "kernel_ms": kernel_ms, "prefilter_ms": coarse_ms,
            "prefilter_TFLOPs": tf, "frac": frac, "d_t": int(d_t), "formula": formula,
            "exact_fallbacks_per_pass": int(st["exact_fallbacks"] / max(1, st["timed_calls"])),
-           "fit_seconds": fit_s, "oracle_check": chk}
+           "fit_seconds": fit_s, "passes_ms": [p[0] * 1e3 for p in passes], "oracle_check": chk}
     assert frac <= 1.0, res
     eng.close()
     del q
@@ -316,13 +323,16 @@ def hamming_config(torch, nq=200_000, n_ref=20_000, n_trees=500, k=5, levels=300
     qd = torch.as_tensor(q, device="cuda")
     dd = torch.empty((nq, k), dtype=torch.float64, device="cuda")
     di = torch.empty((nq, k), dtype=torch.int64, device="cuda")
-    for _ in range(2):
+    passes = []
+    for rep in range(4):  # the first pass warms up; the median of the other three is reported
         ix.reset_stats()
         t0 = time.perf_counter()
         ix.kneighbors_device(qd.data_ptr(), nq, o, dd.data_ptr(), di.data_ptr())
         torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        st = ix.stats()
+        if rep:
+            passes.append((time.perf_counter() - t0, ix.stats()))
+    passes.sort(key=lambda p: p[0])
+    wall, st = passes[1]
     n_chk = min(check_rows, nq)
     od, oi = O.kneighbors_hamming(ref, q[:n_chk], w, k)
     compares = float(n_ref) * nq * n_trees
