@@ -44,7 +44,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30, help="timed passes (default: ~1.5 s of device time, enough for a 1 Hz SMI sampler to see it)")
@@ -63,7 +63,40 @@ def parse_args():
     ap.add_argument("--gather-chunks", type=int, default=2, choices=[1, 2, 3, 4], help="N>1: calls a rank's share is split into (all but the last gather overlap compute)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (self-test of the N>1 path)")
-    return ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="--gpus N > 1 outside a launcher: print the command that would start the N ranks and exit")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (default: a free one)")
+    return ap.parse_args(argv)
+
+
+def launch_command(argv, n_gpus, port):
+    """The command `python bench.py --gpus N` (N > 1, no launcher around it) runs as its child: torch.distributed.run with
+    one rank per GPU on this node, rendezvous on 127.0.0.1, the same bench arguments."""
+    passed = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *passed]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks as CHILD processes
+    (this parent has not touched the GPU -- torch is not even imported yet -- and never re-execs), relay rank 0's JSON
+    line (the children inherit stdout) and exit with the children's status."""
+    import socket
+    import subprocess
+
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = launch_command(argv, args.gpus, port)
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def gen_queries(rows, dims, seed, torch, law="baseline"):
@@ -352,7 +385,10 @@ def hamming_config(torch, nq=200_000, n_ref=20_000, n_trees=500, k=5, levels=300
 
 
 def main():
-    args = parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
     # Libraries print to stdout (RCCL's version banner at communicator creation, for one): the contract is ONE JSON line
     # there, so file descriptor 1 points at stderr until that line is written.
     sys.stdout.flush()
@@ -370,8 +406,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist

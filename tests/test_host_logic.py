@@ -203,3 +203,34 @@ def test_bench_gather_cuts_cover_the_share_in_whole_rounds():
             for a, b in cuts[:-1]:
                 assert b % (256 * 1024) == 0
     assert bench.gather_cuts(1_250_000, 2) == [(0, 786_432), (786_432, 1_250_000)]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` (N > 1) outside a launcher builds a torch.distributed.run child command with one rank
+    per GPU on 127.0.0.1 and the same bench arguments; under a launcher (WORLD_SIZE set) it does not."""
+    import json
+    import subprocess
+    import sys
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "5", "--warmup", "2", "--dry-launch", "--master-port", "29999"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    tail = cmd[cmd.index(bench):]
+    assert tail == [bench, "--gpus", "8", "--steps", "5", "--warmup", "2", "--master-port", "29999"]
+
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", bench)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.launch_command(["--gpus", "2", "--dry-launch"], 2, 1234)[-2:] == ["--gpus", "2"]
+    src = open(bench).read()
+    launch_at, torch_at = src.index("self_launch(args, argv)"), src.index("    import torch\n")
+    assert launch_at < torch_at, "the parent must start its ranks before it imports torch / touches the GPU"
+    assert "os.exec" not in src
