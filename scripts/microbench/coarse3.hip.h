@@ -16,7 +16,7 @@
 //     fragments -- the LDS latency of a tile is covered by the previous tile's MFMAs.
 //   * That costs 24 VGPRs (second cb / hi set): 12 waves per CU (3 per SIMD, <= 168 VGPRs) instead of 16.
 #pragma once
-#include "coarse2.hip.h"
+#include "../../sknnr_amd/csrc/coarse2.hip.h"
 
 namespace sknnr {
 

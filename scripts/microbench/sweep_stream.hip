@@ -12,7 +12,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../sknnr_amd/csrc/coarse3.hip.h"
+#include "coarse3.hip.h"
 
 using namespace sknnr;
 

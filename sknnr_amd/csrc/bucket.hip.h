@@ -58,6 +58,7 @@ struct CellArgs {
 
 // Cell of every row, for calls whose rows no prep kernel has classified (prep_queries_direct_kernel does it on the
 // transformed values it holds in registers).
+#ifdef SKNNR_KERNELS_EXACT
 __global__ void __launch_bounds__(256) cell_assign_kernel(CellArgs a) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q < a.nq) {
@@ -85,8 +86,10 @@ __global__ void __launch_bounds__(256) cell_assign_kernel(CellArgs a) {
         a.cell[q] = (unsigned char)cell_of(z, t);
     }
 }
+#endif  // SKNNR_KERNELS_EXACT
 
 // Rows per cell.
+#ifdef SKNNR_KERNELS_EXACT
 __global__ void __launch_bounds__(kBucketBlock) cell_count_kernel(CellArgs a) {
     __shared__ int h[kCellMax];
     if (threadIdx.x < kCellMax) h[threadIdx.x] = 0;
@@ -96,11 +99,13 @@ __global__ void __launch_bounds__(kBucketBlock) cell_count_kernel(CellArgs a) {
     __syncthreads();
     if (threadIdx.x < kCellMax && h[threadIdx.x] != 0) atomicAdd(&a.hist[threadIdx.x], h[threadIdx.x]);
 }
+#endif  // SKNNR_KERNELS_EXACT
 
 
 // Counting sort by cell: perm[first position of the cell + ticket] = row.  One returning atomic per (block, cell)
 // reserves the block's range; inside the block the rows take tickets from an LDS counter.  The order inside a cell
 // is not deterministic (and does not matter: see the header).
+#ifdef SKNNR_KERNELS_EXACT
 __global__ void __launch_bounds__(kBucketBlock) cell_scatter_kernel(CellArgs a) {
     __shared__ int cnt[kCellMax], base[kCellMax], first[kCellMax];
     const int n_cells = 1 << a.depth;
@@ -127,5 +132,6 @@ __global__ void __launch_bounds__(kBucketBlock) cell_scatter_kernel(CellArgs a) 
     __syncthreads();
     if (q < a.nq) a.perm[first[c] + base[c] + ticket] = (int)q;
 }
+#endif  // SKNNR_KERNELS_EXACT
 
 }  // namespace sknnr

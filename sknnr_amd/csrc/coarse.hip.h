@@ -32,6 +32,14 @@
 
 namespace sknnr {
 
+#if !defined(SKNNR_EXPERIMENTS) && defined(SKNNR_ABLATE_NO_CORR)
+#error "SKNNR_ABLATE_NO_CORR is a timing experiment with wrong results: add -DSKNNR_EXPERIMENTS"
+#endif
+
+// query-row padding of a chunk: a multiple of the rows per workgroup of every pre-filter geometry (2048, 1536, 1024, 768, 512,
+// 384, 256)
+constexpr long kRowQuantum = 6144;
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -153,7 +161,7 @@ __device__ __forceinline__ void list_insert(float (&vals)[M], int (&idxs)[M], fl
 // Development aid (-DSKNNR_COARSE_COUNTERS): event counts of the sweep, summed over waves into
 // coarse_counters[]; read back by sknnr_get_stats and printed to stderr.  Off in the product build.
 #ifdef SKNNR_COARSE_TIMERS
-__device__ unsigned long long coarse_timers[8];
+static __device__ unsigned long long coarse_timers[8];  // (one copy per kernel translation unit)
 #define TICK()                                  \
     do {                                        \
         asm volatile("" ::: "memory");          \
@@ -171,7 +179,7 @@ __device__ unsigned long long coarse_timers[8];
 #define TSTAMP(i) ((void)0)
 #endif
 #ifdef SKNNR_COARSE_COUNTERS
-__device__ unsigned long long coarse_counters[16];
+static __device__ unsigned long long coarse_counters[16];
 #define CTR_ARG , unsigned (&ctr)[16]
 #define CTR_PASS , ctr
 #define CTR(i, n) ctr[i] += (unsigned)(n)

@@ -39,6 +39,13 @@
 #pragma once
 #include "coarse.hip.h"
 
+// Timing experiments that produce WRONG results (sweeps without visits, corrections or stage barriers) compile only in
+// development builds that say so; the product build (sknnr_amd/_build.py) never defines any of them.
+#if !defined(SKNNR_EXPERIMENTS) && (defined(SKNNR_V2_SWEEP_ONLY) || defined(SKNNR_V2_NO_CORR) || defined(SKNNR_V2_NO_BARRIER) || \
+                                    defined(SKNNR_V2_NO_SEED))
+#error "SKNNR_V2_SWEEP_ONLY / NO_CORR / NO_BARRIER / NO_SEED are timing experiments with wrong results: add -DSKNNR_EXPERIMENTS"
+#endif
+
 namespace sknnr {
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));

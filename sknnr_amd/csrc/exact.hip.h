@@ -269,12 +269,14 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
 }
 
 // Finiteness scan of query rows that no prep kernel reads (calls outside the MFMA envelope).
+#ifdef SKNNR_KERNELS_EXACT
 __global__ void __launch_bounds__(256) check_finite_kernel(const double* __restrict__ x, long n, int* status) {
     bool has_nan = false, has_inf = false;
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) classify(x[i], has_nan, has_inf);
     report_nonfinite(status, has_nan, has_inf);
 }
+#endif  // SKNNR_KERNELS_EXACT
 
 // ---------------------------------------------------------------------------------------
 // The reference's pair distance in float64.
@@ -1262,6 +1264,7 @@ __device__ __forceinline__ double np_sum_small(int n, const double (&v)[8]) {
     return r;
 }
 
+#ifdef SKNNR_KERNELS_EXACT
 __global__ void __launch_bounds__(256) predict_kernel(PredictArgs a) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.nq * a.t) return;
@@ -1323,9 +1326,11 @@ __global__ void __launch_bounds__(256) predict_kernel(PredictArgs a) {
     const double den = np_sum(a.k, [&](int i) { return weight(i); });
     a.out[e] = num / den;
 }
+#endif  // SKNNR_KERNELS_EXACT
 
 // Candidate lists of G shards, (G, nq, kk) float64 values and int64 indices as the ranks' all-gather delivers them,
 // into the merge kernel's layout [query][G][kk] (indices as int: a reference set has fewer than 2^31 rows).
+#ifdef SKNNR_KERNELS_EXACT
 __global__ void __launch_bounds__(256)
 pack_shards_kernel(const double* __restrict__ val, const long* __restrict__ idx, long nq, int g_count, int kk,
                    double* __restrict__ slice_v, int* __restrict__ slice_i) {
@@ -1340,14 +1345,18 @@ pack_shards_kernel(const double* __restrict__ val, const long* __restrict__ idx,
         slice_i[o] = (int)idx[src];
     }
 }
+#endif  // SKNNR_KERNELS_EXACT
 
+#ifdef SKNNR_KERNELS_EXACT
 __global__ void __launch_bounds__(256)
 crosswalk_kernel(const long* __restrict__ table, const long* __restrict__ idx, long n, long* __restrict__ out) {
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = table[idx[i]];
 }
+#endif  // SKNNR_KERNELS_EXACT
 
 // Row norms |r|^2 as one fma chain per row (SKL/.../_base.pyx.tp:20-42 uses ddot).
+#ifdef SKNNR_KERNELS_EXACT
 __global__ void __launch_bounds__(256)
 row_norms_kernel(const double* __restrict__ x, long n, int d, double* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1356,5 +1365,6 @@ row_norms_kernel(const double* __restrict__ x, long n, int d, double* __restrict
     for (int c = 0; c < d; ++c) acc = fma(x[i * d + c], x[i * d + c], acc);
     out[i] = acc;
 }
+#endif  // SKNNR_KERNELS_EXACT
 
 }  // namespace sknnr

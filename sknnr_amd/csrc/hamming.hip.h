@@ -114,6 +114,7 @@ struct HammingArgs {
 };
 
 // float64 ids -> packed 16-bit ids [tp][nq_pad]; rows with an id that is not an integer in [0, 65535] are flagged.
+#ifdef SKNNR_KERNELS_HAMMING
 __global__ void __launch_bounds__(256) hamming_pack_kernel(const double* __restrict__ xq, long nq, long nq_pad, int t, int tp,
                                                            uint32_t* __restrict__ qimg, int* __restrict__ q_bad) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -133,7 +134,9 @@ __global__ void __launch_bounds__(256) hamming_pack_kernel(const double* __restr
     }
     q_bad[q] = (q < nq && bad) ? 1 : 0;
 }
+#endif  // SKNNR_KERNELS_HAMMING
 
+#ifdef SKNNR_KERNELS_HAMMING
 __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingArgs a) {
     __shared__ unsigned dbuf[kHamNq][kHamWaves * 64];        // D^ of the step's 256 rows for the 16 queries
     __shared__ unsigned top[kHamNq][kHamMaxKK];              // the kk smallest D^ so far, ascending
@@ -267,6 +270,7 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
         for (int i = lane; i < c; i += 64) a.cand_id[q * kHamCand + i] = cand[j][i];
     }
 }
+#endif  // SKNNR_KERNELS_HAMMING
 
 struct HammingRescoreArgs {
     SelectArgs s;           // s.xq: (nq, d) float64 ids of the queries; s.ref: (n_ref, d) float64 ids; s.hw, s.hw_sum
@@ -282,6 +286,7 @@ struct HammingRescoreArgs {
 // Row-major copy of the references' 16-bit ids for the re-score: [row][tpr] dwords (two ids each), tpr a multiple of 256
 // (one KiB per 512 trees), zeros past the last tree.
 __host__ __device__ constexpr int ham_row_dwords(int t) { return (t + 511) / 512 * 256; }
+#ifdef SKNNR_KERNELS_HAMMING
 __global__ void __launch_bounds__(256) hamming_rows_kernel(const double* __restrict__ x, long n, int t, int tpr, uint32_t* __restrict__ rows) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one dword per thread
     if (i >= n * tpr) return;
@@ -296,6 +301,7 @@ __global__ void __launch_bounds__(256) hamming_rows_kernel(const double* __restr
     }
     rows[i] = packed;
 }
+#endif  // SKNNR_KERNELS_HAMMING
 
 // One wave per query.  The candidates' distances in the reference's float64 arithmetic -- s += w_t for every tree whose ids
 // differ, IN TREE ORDER -- then lane 0 selects by (distance, index) in ascending index order and finishes, exactly as
@@ -307,6 +313,7 @@ __global__ void __launch_bounds__(256) hamming_rows_kernel(const double* __restr
 //            weights from LDS: no memory traffic, the float64 additions are the same chain the reference runs).
 // (Until round 3 every lane walked its own candidate's float64 row, 8 bytes per load out of 64 different rows: 19.3 ms of
 //  the 105 ms of the 200k x 20k x 500 benchmark call.)
+#ifdef SKNNR_KERNELS_HAMMING
 __global__ void __launch_bounds__(256) hamming_rescore_kernel(HammingRescoreArgs a) {
     __shared__ double dv[4][kHamCand];
     __shared__ double hv[4][kHamMaxKK + 2];
@@ -391,6 +398,39 @@ __global__ void __launch_bounds__(256) hamming_rescore_kernel(HammingRescoreArgs
         scan_finish_query<2>(s, q, hv[wave], hi[wave], stack[wave]);
     }
 }
+#endif  // SKNNR_KERNELS_HAMMING
 __host__ inline size_t hamming_rescore_lds(int t) { return (size_t)((t + 1) / 2 * 2) * 8 + (size_t)4 * 64 * ((t + 511) / 512 * 64); }
+
+// Full float64 distance rows of selected queries: out[i][j] = the weighted Hamming distance between query rows[i] and
+// reference row j, in the reference's arithmetic (s += (u != v) * w in tree order, / sum w: scipy's cdist as reached from
+// REF _weighted_trees.py:53-59, :139-140 -- the same chain as exact_scan_kernel<2> and hamming_rescore_kernel).  Serves
+// sknnr_hamming_distances: the rows whose k-th distance is tied are selected on the host by np.argpartition, exactly as
+// SKL/neighbors/_base.py:733-760 (_kneighbors_reduce_func) does, when the caller asks for the reference's own choice
+// among exactly tied rows.
+struct HammingRowsArgs {
+    const double* xq;    // (., d) float64 node ids of the query rows
+    const long* rows;    // (n_rows) which rows of xq, or null: rows 0 .. n_rows - 1
+    long n_rows;
+    const double* refT;  // (d, n_ref) transposed reference ids
+    int d, n_ref;
+    const double* hw;    // (d) weights
+    double hw_sum;       // their sum in index order
+    double* out;         // (n_rows, n_ref)
+};
+#ifdef SKNNR_KERNELS_HAMMING
+__global__ void __launch_bounds__(256) hamming_distance_rows_kernel(HammingRowsArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.n_ref) return;
+    for (long i = blockIdx.y; i < a.n_rows; i += gridDim.y) {
+        const double* x = a.xq + (a.rows ? a.rows[i] : i) * a.d;
+        double acc = 0.0;
+        for (int c = 0; c < a.d; ++c) {
+            const double r = a.refT[(size_t)c * a.n_ref + j];
+            acc = x[c] != r ? acc + a.hw[c] : acc;
+        }
+        a.out[(size_t)i * a.n_ref + j] = acc / a.hw_sum;
+    }
+}
+#endif  // SKNNR_KERNELS_HAMMING
 
 }  // namespace sknnr

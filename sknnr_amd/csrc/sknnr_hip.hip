@@ -1,4 +1,4 @@
-// sknnr_hip.hip -- the C ABI of include/sknnr_hip.h over the gfx950 kernels.
+// sknnr_hip.hip -- the C ABI of include/sknnr_hip.h over the gfx950 kernels (host translation unit).
 //
 // Host side only: index construction (coarse image of the reference rows), workspace,
 // the per-chunk launch sequence  prep -> coarse (MFMA) -> finalize -> exact_scan,
@@ -28,11 +28,9 @@
 #include <thread>
 #include <vector>
 
-#include "bucket.hip.h"
-#include "coarse.hip.h"
-#include "coarse2.hip.h"
-#include "exact.hip.h"
-#include "hamming.hip.h"
+// kernels live in their own translation units (k_*.hip: each defines SKNNR_KERNELS_* for the non-template kernels it owns);
+// this one sees their argument structs and geometry constants only
+#include "launch.hip.h"
 
 using namespace sknnr;
 
@@ -131,7 +129,6 @@ struct DevBuf {
 };
 
 constexpr int kMaxKs = 8;              // coarse path: d <= 128
-constexpr long kRowQuantum = 6144;  // query-row padding: multiple of every coarse geometry (2048, 1536, 1024, 768, 512, 384, 256 rows per workgroup)
 constexpr long kChunkRows = 1L << 22;  // rows per chunk of host-side staging loops (transform entry point, X=None results)
 // Query rows per device chunk of one call (each chunk: prep -> pre-filter -> finalise, padded to kRowQuantum).
 // One launch for as many rows as a 4 GiB workspace holds, at most 2^24: every pre-filter launch ends with a
@@ -705,8 +702,7 @@ extern "C" int sknnr_index_create(const double* ref, int64_t n_ref, int32_t d, c
         HIP_TRY(hipMemcpy(ix->refT.p, tr.data(), nd * sizeof(double), hipMemcpyHostToDevice));
     }
     HIP_TRY(ix->rn64.ensure(n_ref));
-    row_norms_kernel<<<dim3((unsigned)((n_ref + 255) / 256)), dim3(256)>>>(ix->ref64.p, n_ref, d, ix->rn64.p);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch::row_norms(ix->ref64.p, n_ref, d, ix->rn64.p, nullptr));
     if (y) {
         HIP_TRY(ix->y64.ensure((size_t)n_ref * t));
         HIP_TRY(hipMemcpy(ix->y64.p, y, (size_t)n_ref * t * sizeof(double), hipMemcpyHostToDevice));
@@ -1009,8 +1005,7 @@ extern "C" int sknnr_index_set_hamming_weights(sknnr_index* ix, const double* w,
         HIP_TRY(ix->h_rimg.ensure((size_t)tp * ref_pad));
         DevBuf<int> bad;
         HIP_TRY(bad.ensure((size_t)ref_pad));
-        hamming_pack_kernel<<<dim3((unsigned)(ref_pad / 256)), dim3(256)>>>(ix->ref64.p, ix->n_ref, ref_pad, n, tp, ix->h_rimg.p, bad.p);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch::hamming_pack(ix->ref64.p, ix->n_ref, ref_pad, n, tp, ix->h_rimg.p, bad.p, nullptr));
         std::vector<int> hb((size_t)ref_pad);
         HIP_TRY(hipMemcpy(hb.data(), bad.p, (size_t)ref_pad * sizeof(int), hipMemcpyDeviceToHost));
         bool any_bad = false;
@@ -1019,9 +1014,7 @@ extern "C" int sknnr_index_set_hamming_weights(sknnr_index* ix, const double* w,
         bool rows_ok = n <= 4096 && hamming_rescore_lds(n) <= 150 * 1024;
         if (rows_ok) {
             HIP_TRY(ix->h_rrow.ensure((size_t)ix->n_ref * tpr));
-            const long n_dw = (long)ix->n_ref * tpr;
-            hamming_rows_kernel<<<dim3((unsigned)((n_dw + 255) / 256)), dim3(256)>>>(ix->ref64.p, ix->n_ref, n, tpr, ix->h_rrow.p);
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(launch::hamming_rows(ix->ref64.p, ix->n_ref, n, tpr, ix->h_rrow.p, nullptr));
             HIP_TRY(hipDeviceSynchronize());
         }
         ix->h_tp = tp;
@@ -1089,20 +1082,8 @@ extern "C" int sknnr_affine_transform(const double* x, int64_t n, int32_t d_in, 
         a.proj = proj ? dpj.p : nullptr;
         a.xt = dout.p;
         const int ldx = d_in | 1;
-        if ((size_t)256 * ldx * 8 <= 150 * 1024) {
-            const size_t sh = (size_t)256 * ldx * 8;
-            AT_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            prep_queries_kernel<256><<<dim3((unsigned)(a.nq_pad / 256)), dim3(256), sh>>>(a);
-        } else if ((size_t)128 * ldx * 8 <= 150 * 1024) {
-            const size_t sh = (size_t)128 * ldx * 8;
-            AT_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            prep_queries_kernel<128><<<dim3((unsigned)(a.nq_pad / 128)), dim3(128), sh>>>(a);
-        } else {
-            const size_t sh = (size_t)64 * ldx * 8;
-            AT_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            prep_queries_kernel<64><<<dim3((unsigned)(a.nq_pad / 64)), dim3(64), sh>>>(a);
-        }
-        AT_TRY(hipGetLastError());
+        const int bt = (size_t)256 * ldx * 8 <= 150 * 1024 ? 256 : ((size_t)128 * ldx * 8 <= 150 * 1024 ? 128 : 64);
+        AT_TRY(launch::prep_lds(bt, a, nullptr));
         AT_TRY(hipMemcpy(out + c0 * d, dout.p, (size_t)m * d * sizeof(double), hipMemcpyDeviceToHost));
     }
 #undef AT_TRY
@@ -1148,31 +1129,8 @@ extern "C" int sknnr_get_stats(const sknnr_index* cix, sknnr_stats* out) {
     if (hipMemcpy(&total, ix->fail_total.p, sizeof total, hipMemcpyDeviceToHost) == hipSuccess)
         ix->stats.exact_fallbacks = total;
     *out = ix->stats;
-#ifdef SKNNR_COARSE_TIMERS
-    {
-        unsigned long long c[8] = {};
-        (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(sknnr::coarse_timers), sizeof c);
-        // (first kernel: operands_wait, main_no_visit, main_then_visit, correct_and_scan, flush, loop_overhead, barrier;
-        //  second kernel, below: slots 0-4)
-        static const char* names[8] = {"sweep", "visit_scan", "flush", "stage_barrier", "seeding", "-", "-", "wave_total"};
-        for (int i = 0; i < 8; ++i)
-            std::fprintf(stderr, "[coarse-time] %-18s %14llu  %5.1f %%\n", names[i], c[i], 100.0 * (double)c[i] / (double)(c[7] ? c[7] : 1));
-        std::memset(c, 0, sizeof c);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(sknnr::coarse_timers), c, sizeof c);
-    }
-#endif
-#ifdef SKNNR_COARSE_COUNTERS
-    {
-        unsigned long long c[16] = {};
-        (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(sknnr::coarse_counters), sizeof c);
-        static const char* names[16] = {"tile_qblocks", "visits", "group_hits", "member_hits", "hit_lanes", "overflow_inserts",
-                                        "flushes", "flush_iters", "flush_iter_lanes", "flush_insert_iters", "flush_insert_lanes",
-                                        "visit_lanes", "visits_with_true_hit", "", "", ""};
-        for (int i = 0; i < 13; ++i) std::fprintf(stderr, "[coarse] %-22s %llu\n", names[i], c[i]);
-        std::memset(c, 0, sizeof c);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(sknnr::coarse_counters), c, sizeof c);
-    }
-#endif
+    launch::coarse1_dev_report();  // (development builds only: -DSKNNR_COARSE_COUNTERS / -DSKNNR_COARSE_TIMERS)
+    launch::coarse2_dev_report();
     return SKNNR_OK;
 }
 
@@ -1214,8 +1172,6 @@ extern "C" int sknnr_check_finite(sknnr_index* ix, void* stream) {
 // ----------------------------------------------------------------------------------------
 namespace {
 
-__global__ void add_counter_kernel(const int* __restrict__ cnt, long long* __restrict__ total) { *total += *cnt; }
-
 // `cells`: also name every row's cell (query bucketing); *cells_done tells whether this kernel did (the
 // register-resident one does; otherwise the caller runs cell_assign_kernel on the transformed rows)
 int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool affine, double* xt,
@@ -1246,85 +1202,49 @@ int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool aff
             a.cell = ix->qcell.p;
             if (cells_done) *cells_done = true;
         }
-        const dim3 grid((unsigned)(nq_pad / 256)), block(256);
-        switch (ix->ks) {
-            case 1: prep_queries_direct_kernel<1><<<grid, block, 0, st>>>(a); break;
-            case 2: prep_queries_direct_kernel<2><<<grid, block, 0, st>>>(a); break;
-            case 3: prep_queries_direct_kernel<3><<<grid, block, 0, st>>>(a); break;
-            default: prep_queries_direct_kernel<4><<<grid, block, 0, st>>>(a); break;
-        }
+        HIP_TRY(launch::prep_direct(a, st));
     } else if ((size_t)256 * ldx * 8 <= lim) {
-        const size_t sh = (size_t)256 * ldx * 8;
-        HIP_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        prep_queries_kernel<256><<<dim3((unsigned)(nq_pad / 256)), dim3(256), sh, st>>>(a);
+        HIP_TRY(launch::prep_lds(256, a, st));
     } else if ((size_t)128 * ldx * 8 <= lim) {
-        const size_t sh = (size_t)128 * ldx * 8;
-        HIP_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        prep_queries_kernel<128><<<dim3((unsigned)(nq_pad / 128)), dim3(128), sh, st>>>(a);
+        HIP_TRY(launch::prep_lds(128, a, st));
     } else if ((size_t)64 * ldx * 8 <= lim) {
-        const size_t sh = (size_t)64 * ldx * 8;
-        HIP_TRY(hipFuncSetAttribute((const void*)prep_queries_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        prep_queries_kernel<64><<<dim3((unsigned)(nq_pad / 64)), dim3(64), sh, st>>>(a);
+        HIP_TRY(launch::prep_lds(64, a, st));
     } else {
         return fail(SKNNR_ERR_UNSUPPORTED, "d_in = %d is too wide for the query preparation kernel (max 299)", a.d_in);
     }
-    HIP_TRY(hipGetLastError());
     return SKNNR_OK;
 }
 
-template <int KS, int M>
-int launch_coarse_ks(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
-    constexpr int NQB = coarse_nqb(KS, M);
-    constexpr int WAVES = coarse_waves(KS, M);
-    constexpr int QPB = WAVES * NQB * 32;
-    constexpr int TPS = tiles_per_stage(KS);
-    constexpr size_t sh = 2 * (size_t)TPS * tile_bytes(KS) + (size_t)WAVES * queue_bytes_per_wave(NQB, M);
-    static_assert(kRowQuantum % QPB == 0, "query rows are padded to multiples of kRowQuantum");
-    static_assert(sh <= 160 * 1024, "LDS budget");
-    auto kern = coarse_kernel<KS, M>;
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    kern<<<dim3((unsigned)(nq_pad / QPB)), dim3(WAVES * 64), sh, st>>>(
-        ix->rimg.p, ix->n_stages, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
-        M - (kk + 1), ix->cand_val.p, ix->cand_idx.p);
-    HIP_TRY(hipGetLastError());
+// first-generation pre-filter (k_coarse1.hip)
+int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
+    launch::Coarse1Launch L{ix->rimg.p, ix->n_stages, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
+                            m_list - (kk + 1), ix->cand_val.p, ix->cand_idx.p, nq_pad};
+    hipError_t e = hipSuccess;
+    if (launch::coarse1(ix->ks, m_list, L, st, &e) == launch::kNoInstance)
+        return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for ks = %d, list length %d", ix->ks, m_list);
+    HIP_TRY(e);
     return SKNNR_OK;
 }
 
 constexpr int kCoarse2TailWaves = 4;  // workgroup size (waves) of the thin-round variant
 constexpr int kCusPerDevice = 256;
 
-template <int KS, int M, int WAVES>
-int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStream_t st) {
-    constexpr int QPB = WAVES * kCoarse2Nqb * 32;
-    constexpr size_t sh = 2 * (size_t)tiles_per_stage2(KS) * tile2_bytes(KS) + (size_t)WAVES * queue2_bytes_per_wave();
-    static_assert(kRowQuantum % QPB == 0, "query rows are padded to multiples of kRowQuantum");
-    static_assert(sh <= 160 * 1024, "LDS budget");
+int launch_coarse2_waves(sknnr_index* ix, int m_list, int waves, long row0, long rows, int kk, hipStream_t st) {
     // more neighbours than a list holds: thresholds of rank M + E, no sentinels (coarse2_rank_extra)
-    const int extra = coarse2_rank_extra(M, kk);
-    if (extra != 0 && !((M == 16 && kk <= kCoarse2MaxKK16) || (M == 8 && kk <= kCoarse2MaxKK8) || (M == 6 && kk <= kCoarse2MaxKK6)))
-        return fail(SKNNR_ERR_UNSUPPORTED, "lists of %d cannot serve %d neighbours", M, kk);
-    auto kern = coarse2_kernel<KS, M, WAVES, 0>;
-    if constexpr (M == 16) {
-        if (extra == 6) kern = coarse2_kernel<KS, M, WAVES, 6>;
-        else if (extra == 11) kern = coarse2_kernel<KS, M, WAVES, 11>;
-        else if (extra == 15) kern = coarse2_kernel<KS, M, WAVES, 15>;
-        else if (extra == 16) kern = coarse2_kernel<KS, M, WAVES, 16>;
-    } else if constexpr (M == 8) {
-        if (extra == 4) kern = coarse2_kernel<KS, M, WAVES, 4>;
-        else if (extra == 7) kern = coarse2_kernel<KS, M, WAVES, 7>;
-        else if (extra == 8) kern = coarse2_kernel<KS, M, WAVES, 8>;
-    } else if constexpr (M == 6) {
-        if (extra == 3) kern = coarse2_kernel<KS, M, WAVES, 3>;
-    }
-    const bool big = extra != 0;
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    const int extra = coarse2_rank_extra(m_list, kk);
+    if (extra != 0 && !((m_list == 16 && kk <= kCoarse2MaxKK16) || (m_list == 8 && kk <= kCoarse2MaxKK8) || (m_list == 6 && kk <= kCoarse2MaxKK6)))
+        return fail(SKNNR_ERR_UNSUPPORTED, "lists of %d cannot serve %d neighbours", m_list, kk);
     // positions [row0, row0 + rows) of the chunk (bucketed calls: position -> row through qperm, else the row itself)
     const bool bucketed = ix->cell_depth > 0;
-    kern<<<dim3((unsigned)(rows / QPB)), dim3(WAVES * 64), sh, st>>>(
-        ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
-        big ? 0 : M - (kk + 1), ix->cand_val.p, ix->cand_idx.p, (int)row0, bucketed ? ix->qperm.p : nullptr,
-        bucketed ? ix->qcell.p : nullptr, bucketed ? ix->cell_stage.p : nullptr, ix->qlo.p);
-    HIP_TRY(hipGetLastError());
+    launch::Coarse2Launch L{ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
+                            extra != 0 ? 0 : m_list - (kk + 1), ix->cand_val.p, ix->cand_idx.p, (int)row0,
+                            bucketed ? ix->qperm.p : nullptr, bucketed ? ix->qcell.p : nullptr,
+                            bucketed ? ix->cell_stage.p : nullptr, ix->qlo.p, rows};
+    hipError_t e = hipSuccess;
+    if (launch::coarse2(ix->ks, m_list, waves, extra, L, st, &e) == launch::kNoInstance)
+        return fail(SKNNR_ERR_UNSUPPORTED, "no second-generation coarse kernel for ks = %d, list length %d, %d waves, rank + %d", ix->ks,
+                    m_list, waves, extra);
+    HIP_TRY(e);
     return SKNNR_OK;
 }
 
@@ -1334,11 +1254,12 @@ int launch_coarse2_waves(sknnr_index* ix, long row0, long rows, int kk, hipStrea
 // the CUs' worth) go to 4-wave workgroups instead: four times as many CUs, one wave per SIMD.
 // `rows`: the live rows of the chunk -- its padding rows (up to kRowQuantum - 1 of them, behind the live ones also in a
 // bucketed call) get no workgroups of their own: a 262,144-row call is 256 workgroups, not 258 with a thin round of two.
-template <int KS, int M>
-int launch_coarse2_ks(sknnr_index* ix, long rows, int kk, hipStream_t st) {
-    constexpr int BULK_WAVES = coarse2_waves(KS, M);
-    constexpr long QPB = BULK_WAVES * kCoarse2Nqb * 32;
-    constexpr long QPB_TAIL = kCoarse2TailWaves * kCoarse2Nqb * 32;
+int launch_coarse2(sknnr_index* ix, long rows, int m_list, int kk, hipStream_t st) {
+    if (!coarse2_supported(ix->ks, m_list))
+        return fail(SKNNR_ERR_UNSUPPORTED, "no second-generation coarse kernel for ks = %d, list length %d", ix->ks, m_list);
+    const int BULK_WAVES = coarse2_waves(ix->ks, m_list);
+    const long QPB = BULK_WAVES * kCoarse2Nqb * 32;
+    const long QPB_TAIL = kCoarse2TailWaves * kCoarse2Nqb * 32;
     static const bool split = [] {
         const char* e = std::getenv("SKNNR_COARSE_TAIL");
         return !(e && std::atoi(e) == 0);
@@ -1349,7 +1270,7 @@ int launch_coarse2_ks(sknnr_index* ix, long rows, int kk, hipStream_t st) {
     const long bulk_rows = (n_wg - tail_wg) * QPB;
     ix->bulk_rows_done = 0;
     if (bulk_rows > 0) {
-        int rc = launch_coarse2_waves<KS, M, BULK_WAVES>(ix, 0, bulk_rows, kk, st);
+        int rc = launch_coarse2_waves(ix, m_list, BULK_WAVES, 0, bulk_rows, kk, st);
         if (rc) return rc;
         if (tail_wg > 0 && ix->ev_fork) {  // the caller finalises these rows beside the thin round
             if (ix->ev_bulk_end) {  // the timed region ends here: the thin round shares the device from now on
@@ -1362,7 +1283,7 @@ int launch_coarse2_ks(sknnr_index* ix, long rows, int kk, hipStream_t st) {
     }
     if (tail_wg > 0) {
         const long tail_rows = std::min(tail_wg * QPB, (rows - bulk_rows + QPB_TAIL - 1) / QPB_TAIL * QPB_TAIL);
-        return launch_coarse2_waves<KS, M, kCoarse2TailWaves>(ix, bulk_rows, tail_rows, kk, st);
+        return launch_coarse2_waves(ix, m_list, kCoarse2TailWaves, bulk_rows, tail_rows, kk, st);
     }
     return SKNNR_OK;
 }
@@ -1378,23 +1299,6 @@ bool use_coarse2(const sknnr_index* ix, int m_list) {
     // (and the flush addresses the image with 32-bit offsets)
     const long tiles2 = (long)ix->n_stages2 * tiles_per_stage2(ix->ks);
     return enabled && tiles2 >= 2 * kSeedTiles && tiles2 * tile2_bytes(ix->ks) < (1L << 32) && coarse2_supported(ix->ks, m_list);
-}
-
-int launch_coarse2(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {  // (nq_pad: the live rows, see launch_coarse2_ks)
-    if (ix->ks == 1 && m_list == 2) return launch_coarse2_ks<1, 2>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 2) return launch_coarse2_ks<2, 2>(ix, nq_pad, kk, st);
-    if (ix->ks == 1 && m_list == 6) return launch_coarse2_ks<1, 6>(ix, nq_pad, kk, st);
-    if (ix->ks == 1 && m_list == 8) return launch_coarse2_ks<1, 8>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 6) return launch_coarse2_ks<2, 6>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 8) return launch_coarse2_ks<2, 8>(ix, nq_pad, kk, st);
-    if (ix->ks == 1 && m_list == 16) return launch_coarse2_ks<1, 16>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 16) return launch_coarse2_ks<2, 16>(ix, nq_pad, kk, st);
-#ifndef SKNNR_DEV_ONLY_KS2_M6
-    if (ix->ks == 3 && m_list == 6) return launch_coarse2_ks<3, 6>(ix, nq_pad, kk, st);
-    if (ix->ks == 3 && m_list == 8) return launch_coarse2_ks<3, 8>(ix, nq_pad, kk, st);
-    if (ix->ks == 4 && m_list == 6) return launch_coarse2_ks<4, 6>(ix, nq_pad, kk, st);
-#endif
-    return fail(SKNNR_ERR_UNSUPPORTED, "no second-generation coarse kernel for ks = %d, list length %d", ix->ks, m_list);
 }
 
 // List length per lane for kk neighbours searched: at least one spare slot keeps the certificate
@@ -1419,65 +1323,13 @@ int coarse_list_len(const sknnr_index* ix, int kk) {
 }
 int coarse_rank_extra(int m_list, int kk) { return coarse2_rank_extra(m_list, kk); }
 
-#ifdef SKNNR_DEV_ONLY_KS2_M6  // development builds: only the bench's instantiation (fast compile)
-int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
-    if (ix->ks == 1 && m_list == 6) return launch_coarse_ks<1, 6>(ix, nq_pad, kk, st);
-    if (ix->ks == 1 && m_list == 2) return launch_coarse_ks<1, 2>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 2) return launch_coarse_ks<2, 2>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 6) return launch_coarse_ks<2, 6>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 8) return launch_coarse_ks<2, 8>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 16) return launch_coarse_ks<2, 16>(ix, nq_pad, kk, st);
-    if (ix->ks == 2 && m_list == 32) return launch_coarse_ks<2, 32>(ix, nq_pad, kk, st);
-    return fail(SKNNR_ERR_UNSUPPORTED, "development build: ks = 2 only");
-}
-#else
-template <int M>
-int launch_coarse_m(sknnr_index* ix, long nq_pad, int kk, hipStream_t st) {
-    switch (ix->ks) {
-        case 1: return launch_coarse_ks<1, M>(ix, nq_pad, kk, st);
-        case 2: return launch_coarse_ks<2, M>(ix, nq_pad, kk, st);
-        case 3: return launch_coarse_ks<3, M>(ix, nq_pad, kk, st);
-        case 4: return launch_coarse_ks<4, M>(ix, nq_pad, kk, st);
-        case 5: return launch_coarse_ks<5, M>(ix, nq_pad, kk, st);
-        case 6: return launch_coarse_ks<6, M>(ix, nq_pad, kk, st);
-        case 7: return launch_coarse_ks<7, M>(ix, nq_pad, kk, st);
-        case 8: return launch_coarse_ks<8, M>(ix, nq_pad, kk, st);
-    }
-    return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for ks = %d", ix->ks);
-}
-
-int launch_coarse(sknnr_index* ix, long nq_pad, int m_list, int kk, hipStream_t st) {
-    switch (m_list) {
-        case 2: return launch_coarse_m<2>(ix, nq_pad, kk, st);
-        case 6: return launch_coarse_m<6>(ix, nq_pad, kk, st);
-        case 8: return launch_coarse_m<8>(ix, nq_pad, kk, st);
-        case 16: return launch_coarse_m<16>(ix, nq_pad, kk, st);
-        case 32: return launch_coarse_m<32>(ix, nq_pad, kk, st);
-    }
-    return fail(SKNNR_ERR_UNSUPPORTED, "no coarse kernel for list length %d", m_list);
-}
-
-#endif
-
-template <int M>
-void launch_finalize_m(const FinalizeArgs& f, long n, hipStream_t st) {
-    const long threads = n * 2 * M;
-    finalize_kernel<M><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(f);
-}
-void launch_finalize(const FinalizeArgs& f, long n, hipStream_t st) {
-    if (f.m_list <= 8) launch_finalize_m<8>(f, n, st);
-    else if (f.m_list == 16) launch_finalize_m<16>(f, n, st);
-    else launch_finalize_m<32>(f, n, st);
-}
+void launch_finalize(const FinalizeArgs& f, long n, hipStream_t st) { (void)launch::finalize(f, n, st); }
 
 constexpr int kScanGridWg = 256 * 4;  // workgroups of a scan launch (also what scan_slices splits among the passes)
 
-template <int FORMULA>
 int launch_scan_formula(sknnr_index* ix, const ScanArgs& a0, long max_items, bool chunked, size_t sh, hipStream_t st) {
-    constexpr int nq_pass = scan_nq(FORMULA);
     const SelectArgs& s = a0.s;
-    auto kern = chunked ? exact_scan_kernel<FORMULA, true> : exact_scan_kernel<FORMULA, false>;
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    const int nq_pass = scan_nq(s.formula);
     ScanArgs a = a0;
     // Few queries: their passes would leave most of the device idle while each sweeps every reference row
     // (0.5 ms at 50k rows whatever the count) -- the kernel then splits the rows of a pass over several
@@ -1499,15 +1351,13 @@ int launch_scan_formula(sknnr_index* ix, const ScanArgs& a0, long max_items, boo
     const long passes = (max_items + nq_pass - 1) / nq_pass;
     // (sliced mode needs the whole grid even for one pass; otherwise one workgroup per pass is enough)
     const long blocks = may_slice ? kScanGridWg : std::max<long>(1, std::min<long>(passes, kScanGridWg));
-    kern<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(a);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch::exact_scan(s.formula, chunked, a, blocks, sh, st));
     if (!may_slice) return SKNNR_OK;
     // one wave per sliced query (none if the scan was not sliced: the kernel returns at once)
     const long sliced_max = std::min<long>(max_items, (long)kScanGridWg * nq_pass / 2);
     const int kkp = (s.kk + 2) & ~1, stk = (2 * s.kk + 4 + 1) & ~1;
     const size_t msh = 4 * ((size_t)12 * kkp + (size_t)4 * stk);
-    scan_merge_kernel<FORMULA><<<dim3((unsigned)((sliced_max + 3) / 4)), dim3(256), msh, st>>>(a, (int)blocks, 0);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch::scan_merge(s.formula, a, (sliced_max + 3) / 4, msh, (int)blocks, 0, st));
     // queries whose merged heaps are not unique (exact ties): the sequential scan, never sliced
     ScanArgs b = a0;
     b.list = ix->fail_list2.p;
@@ -1515,8 +1365,7 @@ int launch_scan_formula(sknnr_index* ix, const ScanArgs& a0, long max_items, boo
     b.slice_v = nullptr;
     b.slice_i = nullptr;
     const long blocks2 = std::max<long>(1, std::min<long>((sliced_max + nq_pass - 1) / nq_pass, kScanGridWg));
-    kern<<<dim3((unsigned)blocks2), dim3(kScanWaves * 64), sh, st>>>(b);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch::exact_scan(s.formula, chunked, b, blocks2, sh, st));
     return SKNNR_OK;
 }
 
@@ -1527,11 +1376,7 @@ int launch_scan(sknnr_index* ix, const SelectArgs& s, const int* list, const int
         return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", s.k, s.d);
     ScanArgs a{s, ix->refT.p, list, count, nullptr, nullptr, nullptr, nullptr};
     const bool chunked = s.d > kScanColChunk;  // wide rows (tree node ids) are swept in column chunks
-    switch (s.formula) {
-        case 0: return launch_scan_formula<0>(ix, a, max_items, chunked, sh, st);
-        case 1: return launch_scan_formula<1>(ix, a, max_items, chunked, sh, st);
-        default: return launch_scan_formula<2>(ix, a, max_items, chunked, sh, st);
-    }
+    return launch_scan_formula(ix, a, max_items, chunked, sh, st);
 }
 
 struct CallCtx {
@@ -1656,8 +1501,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     if (check_finite && !(coarse || affine)) {
         // no prep kernel reads the rows on this path: scan them here
         const long n_el = nq * (long)d_x;
-        check_finite_kernel<<<dim3((unsigned)std::min<long>((n_el + 255) / 256, 256L * 16)), dim3(256), 0, st>>>(xdev, n_el, ix->status.p);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch::check_finite(xdev, n_el, ix->status.p, st));
     }
     for (long c0 = 0; c0 < nq; c0 += chunk) {
         const long n = std::min(chunk, nq - c0);
@@ -1694,10 +1538,9 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             ca.hist = ix->cell_hist.p;
             ca.perm = ix->qperm.p;
             HIP_TRY(hipMemsetAsync(ix->cell_hist.p, 0, 2 * kCellMax * sizeof(int), st));
-            if (!cells_done) cell_assign_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(ca);
-            cell_count_kernel<<<dim3((unsigned)((n + kBucketBlock - 1) / kBucketBlock)), dim3(kBucketBlock), 0, st>>>(ca);
-            cell_scatter_kernel<<<dim3((unsigned)((n_pad + kBucketBlock - 1) / kBucketBlock)), dim3(kBucketBlock), 0, st>>>(ca);
-            HIP_TRY(hipGetLastError());
+            if (!cells_done) HIP_TRY(launch::cell_assign(ca, st));
+            HIP_TRY(launch::cell_count(ca, st));
+            HIP_TRY(launch::cell_scatter(ca, st));
         }
         HIP_TRY(hipEventRecord(ev.first, st));
         if (v2 && !ix->st_side && !std::getenv("SKNNR_NO_SIDE_STREAM")) {
@@ -1797,8 +1640,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
         for (long c0 = 0; c0 < nq; c0 += chunk_q) {
             const long n = std::min(chunk_q, nq - c0);
             const long n_pad = (n + 255) / 256 * 256;
-            hamming_pack_kernel<<<dim3((unsigned)(n_pad / 256)), dim3(256), 0, st>>>(xq_call + c0 * ix->d, n, n_pad, ix->d, ix->h_tp,
-                                                                                      ix->h_qimg.p, ix->h_bad.p);
+            HIP_TRY(launch::hamming_pack(xq_call + c0 * ix->d, n, n_pad, ix->d, ix->h_tp, ix->h_qimg.p, ix->h_bad.p, st));
             HammingArgs ha{};
             ha.rimg = ix->h_rimg.p;
             ha.wq = ix->h_wq.p;
@@ -1813,7 +1655,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             ha.band = (unsigned)ix->d + 2u;
             ha.cand_cnt = ix->h_cand_cnt.p;
             ha.cand_id = ix->h_cand_id.p;
-            hamming_coarse_kernel<<<dim3((unsigned)((n + kHamNq - 1) / kHamNq)), dim3(kHamWaves * 64), 0, st>>>(ha);
+            HIP_TRY(launch::hamming_coarse(ha, st));
             HammingRescoreArgs hr{};
             hr.s = call;
             hr.s.xq = xq_call + c0 * ix->d;
@@ -1828,10 +1670,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
             hr.fail_base = (int)c0;
             hr.rrow = ix->h_rrow.p;
             hr.tpr = ham_row_dwords(ix->d);
-            const size_t rs_sh = hamming_rescore_lds(ix->d);
-            HIP_TRY(hipFuncSetAttribute((const void*)hamming_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_sh));
-            hamming_rescore_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), rs_sh, st>>>(hr);
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(launch::hamming_rescore(hr, st));
         }
     }
     // One exact scan per call: the rows the finaliser could not certify (call-relative ids), or
@@ -1841,8 +1680,7 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     if (rc) return rc;
     if (coarse) {
         // keep a running total on the device; sknnr_get_stats reads it (no sync here)
-        add_counter_kernel<<<dim3(1), dim3(1), 0, st>>>(ix->fail_count.p, ix->fail_total.p);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch::add_counter(ix->fail_count.p, ix->fail_total.p, st));
         ix->stats.coarse_queries += nq;
     } else {
         ix->stats.exact_only_queries += nq;
@@ -2319,25 +2157,20 @@ extern "C" int sknnr_shard_candidates(sknnr_index* ix, const double* q, int64_t 
 
 namespace {
 
-template <int FORMULA>
 int merge_shards_formula(sknnr_index* ix, const SelectArgs& call, int n_shards, long nq, hipStream_t st) {
     ScanArgs a{call, ix->refT.p, nullptr, nullptr, ix->slice_v.p, ix->slice_i.p, ix->fail_list2.p, ix->fail_count.p + 2};
     const int kkp = (call.kk + 2) & ~1, stk = (2 * call.kk + 4 + 1) & ~1;
     const size_t msh = 4 * ((size_t)12 * kkp + (size_t)4 * stk);
-    scan_merge_kernel<FORMULA><<<dim3((unsigned)((nq + 3) / 4)), dim3(256), msh, st>>>(a, 0, n_shards);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch::scan_merge(call.formula, a, (nq + 3) / 4, msh, 0, n_shards, st));
     // rows whose merged answer is not unique (exact ties that the reference's heap settles by its history): the
     // sequential scan over ALL reference rows of this handle, as for any other tied row
     const size_t sh = scan_block_bytes(call.d, call.kk, call.formula);
     if (sh > 150 * 1024) return fail(SKNNR_ERR_UNSUPPORTED, "n_neighbors = %d with d = %d does not fit the exact scan kernel", call.k, call.d);
     ScanArgs b{call, ix->refT.p, ix->fail_list2.p, ix->fail_count.p + 2, nullptr, nullptr, nullptr, nullptr};
     const bool chunked = call.d > kScanColChunk;
-    auto kern = chunked ? exact_scan_kernel<FORMULA, true> : exact_scan_kernel<FORMULA, false>;
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    constexpr int nq_pass = scan_nq(FORMULA);
+    const int nq_pass = scan_nq(call.formula);
     const long blocks = std::max<long>(1, std::min<long>((nq + nq_pass - 1) / nq_pass, kScanGridWg));
-    kern<<<dim3((unsigned)blocks), dim3(kScanWaves * 64), sh, st>>>(b);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch::exact_scan(call.formula, chunked, b, blocks, sh, st));
     return SKNNR_OK;
 }
 
@@ -2390,15 +2223,8 @@ int merge_shards_device(sknnr_index* ix, const double* xdev, long nq, const sknn
     HIP_TRY(ix->slice_i.ensure(heaps));
     HIP_TRY(ix->fail_list2.ensure((size_t)nq));
     HIP_TRY(hipMemsetAsync(ix->fail_count.p, 0, 16, st));
-    pack_shards_kernel<<<dim3((unsigned)std::min<long>(((long)heaps + 255) / 256, 256L * 32)), dim3(256), 0, st>>>(
-        shard_val, shard_idx, nq, n_shards, kk, ix->slice_v.p, ix->slice_i.p);
-    HIP_TRY(hipGetLastError());
-    int rc;
-    switch (o->formula) {
-        case 0: rc = merge_shards_formula<0>(ix, call, n_shards, nq, st); break;
-        case 1: rc = merge_shards_formula<1>(ix, call, n_shards, nq, st); break;
-        default: rc = merge_shards_formula<2>(ix, call, n_shards, nq, st); break;
-    }
+    HIP_TRY(launch::pack_shards(shard_val, shard_idx, nq, n_shards, kk, ix->slice_v.p, ix->slice_i.p, st));
+    int rc = merge_shards_formula(ix, call, n_shards, nq, st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ix->ev_ws, st));
     ix->ws_busy = true;
@@ -2463,9 +2289,7 @@ static int launch_predict(sknnr_index* ix, const double* dist, const long* idx, 
     a.t = ix->t;
     a.mode = mode;
     a.out = out;
-    const long total = nq * ix->t;
-    predict_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(a);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch::predict(a, st));
     // the reduction may read the handle's staging buffers: it is now the workspace's last user
     HIP_TRY(hipEventRecord(ix->ev_ws, st));
     ix->ws_busy = true;
@@ -2640,10 +2464,8 @@ extern "C" int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int6
     if (mem != SKNNR_MEM_DEVICE && mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
     if (n == 0) return SKNNR_OK;
     HIP_TRY(hipSetDevice(device));
-    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 256L * 16);
     if (mem == SKNNR_MEM_DEVICE) {
-        crosswalk_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>((const long*)table, (const long*)idx, n, (long*)out);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch::crosswalk((const long*)table, (const long*)idx, n, (long*)out, (hipStream_t)stream));
         return SKNNR_OK;
     }
     DevBuf<long> dt, di, dout;  // freed by their destructors on every return path
@@ -2652,8 +2474,7 @@ extern "C" int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int6
     HIP_TRY(dout.ensure(n));
     HIP_TRY(hipMemcpy(dt.p, table, n_table * sizeof(long), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(di.p, idx, n * sizeof(long), hipMemcpyHostToDevice));
-    crosswalk_kernel<<<dim3(blocks), dim3(256)>>>(dt.p, di.p, n, dout.p);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch::crosswalk(dt.p, di.p, n, dout.p, nullptr));
     HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(long), hipMemcpyDeviceToHost));
     return SKNNR_OK;
 }
@@ -2661,11 +2482,6 @@ extern "C" int sknnr_crosswalk(const int64_t* table, int64_t n_table, const int6
 // ----------------------------------------------------------------------------------------
 // diagnostics
 // ----------------------------------------------------------------------------------------
-template <int KS>
-static void launch_matrix(sknnr_index* ix, long n_tiles, long nqb, long nq, float* out) {
-    coarse_matrix_kernel<KS><<<dim3((unsigned)n_tiles, (unsigned)nqb), dim3(64)>>>(ix->rimg.p, ix->perm.p, ix->qimg.p, (int)ix->n_ref, (int)nq, out);
-}
-
 extern "C" int sknnr_debug_coarse_matrix(sknnr_index* ix, const double* q, int64_t nq, float* out, double* out_qnorm,
                                          double* out_scale, double* out_eps) {
     if (!ix || !q || !out || nq < 1) return fail(SKNNR_ERR_INVALID, "bad argument");
@@ -2684,17 +2500,7 @@ extern "C" int sknnr_debug_coarse_matrix(sknnr_index* ix, const double* q, int64
     DevBuf<float> dout;
     HIP_TRY(dout.ensure((size_t)nq * ix->n_ref));
     const long n_tiles = (ix->n_ref + 31) / 32, nqb = (nq + 31) / 32;
-    switch (ix->ks) {
-        case 1: launch_matrix<1>(ix, n_tiles, nqb, nq, dout.p); break;
-        case 2: launch_matrix<2>(ix, n_tiles, nqb, nq, dout.p); break;
-        case 3: launch_matrix<3>(ix, n_tiles, nqb, nq, dout.p); break;
-        case 4: launch_matrix<4>(ix, n_tiles, nqb, nq, dout.p); break;
-        case 5: launch_matrix<5>(ix, n_tiles, nqb, nq, dout.p); break;
-        case 6: launch_matrix<6>(ix, n_tiles, nqb, nq, dout.p); break;
-        case 7: launch_matrix<7>(ix, n_tiles, nqb, nq, dout.p); break;
-        case 8: launch_matrix<8>(ix, n_tiles, nqb, nq, dout.p); break;
-    }
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch::coarse_matrix(ix->ks, ix->rimg.p, ix->perm.p, ix->qimg.p, (int)ix->n_ref, nq, n_tiles, nqb, dout.p);
     if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)nq * ix->n_ref * sizeof(float), hipMemcpyDeviceToHost);
     if (e == hipSuccess && out_qnorm) e = hipMemcpy(out_qnorm, ix->qnc.p, nq * sizeof(double), hipMemcpyDeviceToHost);
     dout.release();
