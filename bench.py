@@ -602,14 +602,28 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
 
     # ---- the headline workload entered from host arrays (PCIe-inclusive; never `value`) ----------
     q_host = q.cpu().numpy()
+    median = lambda xs: float(np.median(np.asarray(xs, dtype=np.float64)))  # noqa: E731
     walls = []
-    for _ in range(4):  # (the first call allocates the pinned staging buffers)
+    for _ in range(6):  # (the first call allocates the pinned staging buffers: not counted)
         wall, (hd, hi) = timed(lambda: eng.kneighbors(q_host, k, apply_affine=True), torch, steps=1, warmup=0)
         walls.append(wall)
-    out["host_to_host_Mq_s"] = nq / min(walls[1:]) / 1e6
+    out["host_to_host_Mq_s"] = nq / median(walls[1:]) / 1e6
     out["host_to_host_calls_ms"] = [w * 1e3 for w in walls]
-    out["host_to_host_note"] = ("numpy rows in, fresh numpy (dist, idx) out; best of the three calls after the first, every call's time listed; "
+    out["host_to_host_note"] = ("numpy rows in, fresh numpy (dist, idx) out; MEDIAN of the five calls after the first, every call's time listed; "
                                 "allocation and first-touch faults of the 800 MB of outputs are inside (they vary by tens of ms with the host's page state)")
+    # the same rows as float32 (what a raster usually holds): widened by the prep kernel, half the PCIe bytes in
+    q_f32 = q_host.astype(np.float32)
+    q_back = torch.as_tensor(q_f32.astype(np.float64), device="cuda")
+    ref_d, ref_i = eng.kneighbors(q_back, k, apply_affine=True)
+    walls32 = []
+    for _ in range(6):
+        wall, (hd32, hi32) = timed(lambda: eng.kneighbors(q_f32, k, apply_affine=True), torch, steps=1, warmup=0)
+        walls32.append(wall)
+    out["host_to_host_f32_Mq_s"] = nq / median(walls32[1:]) / 1e6
+    out["host_to_host_f32_calls_ms"] = [w * 1e3 for w in walls32]
+    out["host_to_host_f32_note"] = ("float32 numpy rows in (sknnr_query_opts.query_dtype = F32: widened on the device, exactly); median of five; "
+                                    f"equal to the float64 call on the widened rows: {bool(np.array_equal(hi32, ref_i.cpu().numpy()) and np.array_equal(hd32, ref_d.cpu().numpy()))}")
+    del q_f32, q_back, ref_d, ref_i, hd32, hi32
     tile = 1_000_000
     d_st = np.empty((nq, k))
     i_st = np.empty((nq, k), dtype=np.int64)
@@ -621,8 +635,9 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
         return None
 
     timed(stream_run, torch, steps=1, warmup=0)  # (the warm-up pass touches the caller-owned output arrays)
-    wall = min(timed(stream_run, torch, steps=1, warmup=0)[0] for _ in range(2))  # best of two, as for the one-shot call
-    out["stream_Mq_s"] = nq / wall / 1e6
+    st_walls = [timed(stream_run, torch, steps=1, warmup=0)[0] for _ in range(5)]
+    out["stream_Mq_s"] = nq / median(st_walls) / 1e6
+    out["stream_calls_ms"] = [w * 1e3 for w in st_walls]
     out["stream_note"] = (f"{-(-nq // tile)} pushes of {tile} rows through sknnr_stream_*; equals the one-call result: "
                           f"{bool(np.array_equal(i_st, hi) and np.array_equal(d_st, hd))}")
     del d_st, i_st, hd, hi
@@ -637,8 +652,9 @@ def extras(args, eng, q, x_ref_t, affine, torch, device):
     est = sknnr_amd.GNNRegressor(n_neighbors=k).fit(x_ref, y)
     est_fit = time.perf_counter() - t0
     timed(lambda: est.kneighbors(q_host), torch, steps=1, warmup=0)
-    wall = min(timed(lambda: est.kneighbors(q_host), torch, steps=1, warmup=0)[0] for _ in range(3))  # best of three (host page state)
-    out["estimator_Mq_s"] = nq / wall / 1e6
+    est_walls = [timed(lambda: est.kneighbors(q_host), torch, steps=1, warmup=0)[0] for _ in range(5)]
+    out["estimator_Mq_s"] = nq / median(est_walls) / 1e6
+    out["estimator_calls_ms"] = [w * 1e3 for w in est_walls]
     out["estimator_note"] = (f"GNNRegressor(n_neighbors={k}).fit in {est_fit:.2f} s (incl. independent prediction), "
                              "kneighbors(X_numpy) wall: sklearn validate_data (no host finiteness pass) + host pipeline")
     del est, q_host

@@ -32,7 +32,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden; exactly these declarations are exported. */
 #pragma GCC visibility push(default)
 
-#define SKNNR_ABI_VERSION 4
+#define SKNNR_ABI_VERSION 5
 
 typedef enum sknnr_status {
     SKNNR_OK = 0,
@@ -68,10 +68,27 @@ typedef enum sknnr_formula {
                                    :139-140 (metric_params={"w": hamming_weights_}) through
                                    SKL/neighbors/_base.py:896-926 (pairwise_distances_chunked +
                                    _kneighbors_reduce_func).  No square root; rows tied exactly at the k-th
-                                   distance are taken lowest index first (numpy's argpartition leaves that
-                                   choice to its introselect: INTEGRATION.md, "Hamming ties").  Needs
-                                   sknnr_index_set_hamming_weights. */
+                                   distance are taken lowest index first.  The reference takes what numpy's
+                                   argpartition takes; a caller that wants exactly that choice gets the tied
+                                   rows' full distance rows from sknnr_hamming_distances and runs argpartition
+                                   on them (the Python layer's hamming_tie_policy("numpy"); INTEGRATION.md,
+                                   "Hamming ties").  Needs sknnr_index_set_hamming_weights. */
 } sknnr_formula;
+
+/* Element type of the query rows handed to kneighbors / predict / a stream (opts->query_dtype).  Rasters come as
+ * float32 / int16 / uint8 ...; the reference widens them to float64 on the host before any arithmetic
+ * (validate_data(..., dtype=FLOAT_DTYPES) then `X - env_center_` in float64: REF transformers/_cca_transformer.py:78-87,
+ * _ccora_transformer.py:67-70; integers become float64 in every transformer).  Here the kernel that reads the rows
+ * widens them -- exact for every type below, so the results are those of the float64 call bit for bit -- and the rows
+ * cross PCIe at their own width. */
+typedef enum sknnr_dtype {
+    SKNNR_DTYPE_F64 = 0,
+    SKNNR_DTYPE_F32 = 1,
+    SKNNR_DTYPE_I16 = 2,
+    SKNNR_DTYPE_U16 = 3,
+    SKNNR_DTYPE_U8 = 4,
+    SKNNR_DTYPE_I32 = 5
+} sknnr_dtype;
 
 typedef enum sknnr_weight_mode {
     SKNNR_WEIGHTS_UNIFORM = 0,  /* np.mean over the k neighbours  (SKL/neighbors/_regression.py:254-255) */
@@ -97,6 +114,9 @@ typedef struct sknnr_query_opts {
                               (what validate_data(ensure_all_finite=True) does on the host in the reference).
                               Host-memory calls then fail with SKNNR_ERR_NONFINITE; device-memory calls stay
                               asynchronous and the caller polls sknnr_check_finite() */
+    int32_t query_dtype;   /* sknnr_dtype of the query rows `q` (0 = float64).  Other types need the MFMA envelope
+                              (d <= 128) and a Euclidean formula; they are widened by the kernel that reads them */
+    int32_t reserved_;     /* keep 0 */
     int64_t row_offset;    /* position of query row 0 inside the logical call: key 2 of the reorder is
                               |idx - row| with row counted over the whole call (REF _base.py:171), so a
                               shard or chunk must carry its global offset */
@@ -198,14 +218,14 @@ int sknnr_check_finite(sknnr_index* index, void* stream);
  * k nearest reference rows of each query row.
  * Replaces RawKNNRegressor.kneighbors (REF _base.py:111-182) = sklearn's
  * KNeighborsMixin.kneighbors (SKL/neighbors/_base.py:763-963) + sknnr's reorder.
- *   q        : (nq, d_in or d) float64 in `mem`, or NULL with opts->exclude_self = 1
- *              (the query rows are then the handle's own reference rows)
+ *   q        : (nq, d_in or d) rows of opts->query_dtype (float64 unless set) in `mem`, or NULL with
+ *              opts->exclude_self = 1 (the query rows are then the handle's own reference rows)
  *   out_dist : (nq, k) float64 in `mem`, ascending / reordered distances; may be NULL
  *   out_idx  : (nq, k) int64 in `mem`, reference row indices
  *   stream   : hipStream_t to launch on when mem == SKNNR_MEM_DEVICE (NULL = default stream);
  *              ignored for host buffers (the call then returns after the copy-back)
  */
-int sknnr_kneighbors(sknnr_index* index, const double* q, int64_t nq,
+int sknnr_kneighbors(sknnr_index* index, const void* q, int64_t nq,
                      const sknnr_query_opts* opts, double* out_dist, int64_t* out_idx,
                      int32_t mem, void* stream);
 
@@ -217,7 +237,7 @@ int sknnr_kneighbors(sknnr_index* index, const double* q, int64_t nq,
  *   out_dist, out_idx : optional (nq, k) outputs of the underlying kneighbors (NULL to skip)
  * With opts->weight_mode == SKNNR_WEIGHTS_EXPLICIT use sknnr_predict_from_neighbors instead.
  */
-int sknnr_predict(sknnr_index* index, const double* q, int64_t nq, const sknnr_query_opts* opts,
+int sknnr_predict(sknnr_index* index, const void* q, int64_t nq, const sknnr_query_opts* opts,
                   double* out_pred, double* out_dist, int64_t* out_idx, int32_t mem, void* stream);
 
 /*
@@ -228,6 +248,19 @@ int sknnr_predict(sknnr_index* index, const double* q, int64_t nq, const sknnr_q
 int sknnr_predict_from_neighbors(sknnr_index* index, const double* dist, const int64_t* idx,
                                  const double* w, int64_t nq, int32_t k, int32_t weight_mode,
                                  double* out_pred, int32_t mem, void* stream);
+
+/*
+ * Full weighted-Hamming distance rows: out[i, j] = distance between query row rows[i] and reference row j, in the
+ * reference's float64 arithmetic (sknnr_formula, SKNNR_FORMULA_HAMMING) -- the matrix the reference's brute search
+ * materialises chunk by chunk (SKL/neighbors/_base.py:896-926, pairwise_distances_chunked) before
+ * _kneighbors_reduce_func (SKL/neighbors/_base.py:733-760) runs np.argpartition over each row.  For the rows whose
+ * k-th distance is tied the caller can thus make numpy's own selection (REF tests/test_regressions.py:125-195 pin it).
+ *   q    : (nq, d) float64 node ids in `mem`, or NULL: the handle's reference rows (the X=None path)
+ *   rows : (n_rows) int64 in `mem`: which rows of q; NULL: rows 0 .. n_rows - 1
+ *   out  : (n_rows, n_ref) float64 in `mem`
+ */
+int sknnr_hamming_distances(sknnr_index* index, const double* q, int64_t nq, const int64_t* rows, int64_t n_rows,
+                            double* out, int32_t mem, void* stream);
 
 /* ---- reference-sharded search ------------------------------------------------------------------ */
 
@@ -273,7 +306,7 @@ int sknnr_merge_shards(sknnr_index* index, const double* q, int64_t nq, const sk
  *           the global row of the first pushed row.  want_dist / want_pred say which optional outputs
  *           later pushes may ask for.  One open stream per handle; host-memory kneighbors/predict
  *           calls on the handle fail while it is open (device-memory calls are allowed).
- *   push  : q is a HOST (nq, d_in or d) tile and may be reused as soon as the call returns.  The
+ *   push  : q is a HOST (nq, d_in or d) tile of the stream's opts->query_dtype and may be reused as soon as the call returns.  The
  *           tile's results are written to the HOST buffers passed with it -- out_idx (nq, k), out_dist
  *           (nq, k) or NULL, out_pred (nq, t) or NULL -- at the latest when a flush or end returns (earlier in
  *           practice: a tile leaves its pipeline slot when the slot is needed again, four tiles later);
@@ -286,7 +319,7 @@ int sknnr_merge_shards(sknnr_index* index, const double* q, int64_t nq, const sk
 typedef struct sknnr_stream sknnr_stream;
 int sknnr_stream_begin(sknnr_index* index, const sknnr_query_opts* opts, int32_t want_dist, int32_t want_pred,
                        sknnr_stream** out);
-int sknnr_stream_push(sknnr_stream* stream, const double* q, int64_t nq, double* out_dist, int64_t* out_idx,
+int sknnr_stream_push(sknnr_stream* stream, const void* q, int64_t nq, double* out_dist, int64_t* out_idx,
                       double* out_pred);
 int sknnr_stream_flush(sknnr_stream* stream);
 int sknnr_stream_end(sknnr_stream* stream, int64_t* rows_pushed);

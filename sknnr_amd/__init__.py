@@ -14,6 +14,7 @@ from ._estimators import (
     MSNRegressor,
 )
 
+from ._config import get_hamming_tie_policy, hamming_tie_policy, set_hamming_tie_policy
 from ._forest_nn import GBNNRegressor, RFNNRegressor
 
 __version__ = "0.2.0"
@@ -26,4 +27,4 @@ __all__ = [
     "GNNRegressor",
     "RFNNRegressor",
     "GBNNRegressor",
-]
+]  # (= REF src/sknnr/__init__.py; the backend's own settings -- hamming_tie_policy & co -- are attributes, not exports)

@@ -24,8 +24,14 @@ from sklearn.exceptions import NotFittedError
 from sklearn.metrics import r2_score
 from sklearn.utils.validation import _is_arraylike, check_is_fitted, validate_data
 
-from . import _native
+from . import _config, _native
 from ._engine import KNNEngine, default_device, is_torch_cuda_tensor
+
+# Element types query rows may keep on their way to the device (include/sknnr_hip.h, sknnr_dtype): the kernel that reads
+# them widens to float64, exactly -- the reference's host-side conversion (validate_data(dtype=FLOAT_DTYPES) followed by
+# float64 arithmetic, REF transformers/_cca_transformer.py:78-87) without the host pass and at the rows' own PCIe width.
+# Anything else (int64, bool, float16, ...) is converted to float64 by validate_data as before.
+_QUERY_DTYPES = [np.float64, np.float32, np.int16, np.uint16, np.uint8, np.int32]
 
 _EUCLIDEAN_NAMES = {"euclidean", "l2"}
 _ALGORITHMS = {"auto", "brute", "kd_tree", "ball_tree"}
@@ -67,6 +73,37 @@ def _resolve_fit_method(algorithm, n_ref, d, k):
     if d > 15 or (k is not None and k >= n_ref // 2):
         return "brute"
     return "kd_tree"
+
+
+def replay_reference_selection(full, kk, call_rows, self_query, deterministic, decimals):
+    """The reference's selection on full distance rows, line by line, with this host's numpy.
+
+    ``full`` (n, n_fit): float64 distance rows (computed on the device).  ``kk``: neighbours searched (k, + 1 for the X=None
+    path).  ``call_rows`` (n): each row's position in the whole call (for X=None also its own reference index).
+    Steps: ``_kneighbors_reduce_func`` (SKL/neighbors/_base.py:733-760: argpartition, then argsort of the kept
+    distances), the X=None self removal (SKL/neighbors/_base.py:936-963) and sknnr's deterministic reorder
+    (REF src/sknnr/_base.py:166-175).  Returns ``(dist, idx)`` with k columns.
+    """
+    n = full.shape[0]
+    sample_range = np.arange(n)[:, None]
+    neigh = np.argpartition(full, kk - 1, axis=1)[:, :kk]
+    neigh = neigh[sample_range, np.argsort(full[sample_range, neigh])]
+    nd = full[sample_range, neigh]
+    call_rows = np.asarray(call_rows, dtype=np.int64)
+    if self_query:
+        sample_mask = neigh != call_rows[:, None]
+        dup_gr_nbrs = np.all(sample_mask, axis=1)
+        sample_mask[:, 0][dup_gr_nbrs] = False
+        neigh = np.reshape(neigh[sample_mask], (n, kk - 1))
+        nd = np.reshape(nd[sample_mask], (n, kk - 1))
+    if deterministic:
+        row_scale = np.maximum(nd.max(axis=1, keepdims=True), 1.0)
+        rounded = np.round(nd / row_scale, decimals=decimals)
+        diff = np.abs(neigh - call_rows[:, None])
+        order = np.lexsort((neigh, diff, rounded), axis=1)
+        nd = np.take_along_axis(nd, order, axis=1)
+        neigh = np.take_along_axis(neigh, order, axis=1)
+    return nd, neigh
 
 
 def _reraise(err, estimator):
@@ -202,7 +239,7 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
             return X
         # feature count / names / dtype here; finiteness is tested by the kernels that read the rows
         # (check_finite), not by a second pass over them on the host
-        return validate_data(self, X, reset=False, order="C", dtype=np.float64, ensure_all_finite=False)
+        return validate_data(self, X, reset=False, order="C", dtype=_QUERY_DTYPES, ensure_all_finite=False)
 
     def _resolve_k(self, n_neighbors):
         if n_neighbors is None:
@@ -214,9 +251,61 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
             raise ValueError("Expected n_neighbors > 0. Got %d" % n_neighbors)
         return int(n_neighbors)
 
+    def _numpy_ties(self) -> bool:
+        """RFNN / GBNN under ``hamming_tie_policy("numpy")``: exactly tied rows as the reference's argpartition keeps them."""
+        return (getattr(self, "effective_metric_", "euclidean") == "hamming"
+                and _config.get_hamming_tie_policy() == "numpy")
+
+    def _kneighbors_hamming_numpy_ties(self, X, k, use_deterministic_ordering, row_offset, n_self_rows):
+        """Weighted-Hamming neighbours with the REFERENCE's choice among exactly tied rows.
+
+        The device answers every row (tied rows lowest index first).  A second device search for one neighbour more, on the
+        raw rows, shows which queries have an exact tie that the choice depends on (across the last slot; without the
+        deterministic reorder, anywhere among the kept rows).  For those queries the device returns the full float64
+        distance row (``sknnr_hamming_distances``: the matrix the reference's brute search materialises) and the
+        selection is replayed line by line with this host's numpy: ``_kneighbors_reduce_func``
+        (SKL/neighbors/_base.py:733-760: argpartition, argsort), the X=None self removal (SKL/neighbors/_base.py:936-963)
+        and sknnr's reorder (REF src/sknnr/_base.py:166-175) -- reached in the reference from
+        REF src/sknnr/_weighted_trees.py:53-59, :139-140 and pinned by REF tests/test_regressions.py:125-195.
+        """
+        eng = self.engine_
+        cuda_in = is_torch_cuda_tensor(X)
+        X_host = X.cpu().numpy() if cuda_in else X
+        self_query = X is None
+        kk = k + (1 if self_query else 0)
+        n_fit = self.n_samples_fit_
+        dist, idx = eng.kneighbors(X_host, k, exclude_self=self_query, deterministic=use_deterministic_ordering,
+                                   decimals=self.DISTANCE_PRECISION_DECIMALS, formula="hamming", row_offset=row_offset,
+                                   n_self_rows=n_self_rows, check_finite=X is not None)
+        nq = idx.shape[0]
+        if nq:
+            rows_q = self._fit_X[row_offset:row_offset + nq] if self_query else X_host
+            probe = min(kk + 1, n_fit)
+            pd, _ = eng.kneighbors(rows_q, probe, exclude_self=False, deterministic=False, formula="hamming")
+            if use_deterministic_ordering:  # only the SET of kept rows can differ: a tie across the last slot
+                flagged = pd[:, kk - 1] == pd[:, kk] if probe > kk else np.zeros(nq, dtype=bool)
+            else:  # the order among equal distances is argpartition's too
+                flagged = (pd[:, :-1] == pd[:, 1:]).any(axis=1) if probe > 1 else np.zeros(nq, dtype=bool)
+            rows = np.flatnonzero(flagged)
+            step = max(1, (256 << 20) // (8 * n_fit))  # distance rows of at most ~256 MB at a time
+            for a in range(0, rows.size, step):
+                sel = rows[a:a + step]
+                full = eng.hamming_distances(None if self_query else X_host, sel + (row_offset if self_query else 0))
+                dist[sel], idx[sel] = replay_reference_selection(full, kk, sel + row_offset, self_query,
+                                                                  use_deterministic_ordering,
+                                                                  self.DISTANCE_PRECISION_DECIMALS)
+            self._last_numpy_tie_rows = int(rows.size)
+        if cuda_in:
+            import torch
+
+            return torch.as_tensor(dist, device=X.device), torch.as_tensor(idx, device=X.device)
+        return dist, idx
+
     def _kneighbors_engine(self, X, k, *, apply_affine, use_deterministic_ordering, row_offset=0,
                            n_self_rows=None, return_distance=True, out=None, owner=None):
         try:
+            if self._numpy_ties() and out is None:
+                return self._kneighbors_hamming_numpy_ties(X, k, use_deterministic_ordering, row_offset, n_self_rows)
             return self.engine_.kneighbors(
                 X, k, exclude_self=X is None, deterministic=use_deterministic_ordering,
                 decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
@@ -278,6 +367,25 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
     def _predict_engine(self, X, *, apply_affine, row_offset=0, n_self_rows=None, owner=None):
         weights = None if self.weights is None else self.weights
         try:
+            if self._numpy_ties():
+                # the reference's predict() calls ITS kneighbors (deterministic ordering on): the same neighbours here,
+                # then the reduction on the device (SKL/neighbors/_regression.py:224-268)
+                dist, idx = self._kneighbors_hamming_numpy_ties(X, self.n_neighbors, True, row_offset, n_self_rows)
+                cuda = is_torch_cuda_tensor(dist)
+                if cuda:
+                    dev = dist.device
+                    dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
+                if callable(weights):
+                    w = np.asarray(weights(dist), dtype=np.float64)
+                    pred = self.engine_._index.predict_from_neighbors_host(dist, idx, w, _native.WEIGHTS_EXPLICIT)
+                else:
+                    mode = _native.WEIGHTS_DISTANCE if weights == "distance" else _native.WEIGHTS_UNIFORM
+                    pred = self.engine_._index.predict_from_neighbors_host(dist, idx, None, mode)
+                if cuda:
+                    import torch
+
+                    pred = torch.as_tensor(pred, device=dev)
+                return pred.reshape(-1) if self._y.ndim == 1 else pred
             pred = self.engine_.predict(
                 X, self.n_neighbors, "uniform" if weights is None else weights, exclude_self=X is None,
                 deterministic=True, decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
@@ -305,41 +413,86 @@ class RawKNNRegressor(DFIndexCrosswalkMixin, MultiOutputMixin, RegressorMixin, B
         eng = self.engine_
         want_pred = weights is not None
         t_cols = eng.t
+        if self._numpy_ties():
+            # the reference's choice among tied rows is made on the host, per call: tile by tile, positions carried
+            parts, row = [], 0
+            for tile in tiles:
+                tile = validate(tile)
+                if tile.shape[0] == 0:
+                    continue
+                if want_pred:
+                    parts.append((None, None, np.reshape(self._predict_engine(tile, apply_affine=apply_affine, row_offset=row,
+                                                                               owner=owner), (tile.shape[0], -1))))
+                else:
+                    d_, i_ = self._kneighbors_engine(tile, k, apply_affine=apply_affine, row_offset=row,
+                                                     use_deterministic_ordering=use_deterministic_ordering, owner=owner)
+                    parts.append((d_, i_, None))
+                row += tile.shape[0]
+            cat = lambda j, cols, dt: (np.concatenate([p_[j] for p_ in parts]) if parts  # noqa: E731
+                                       else np.empty((0, cols), dtype=dt))
+            res = (cat(0, k, np.float64) if return_distance and not want_pred else None,
+                   None if want_pred else cat(1, k, np.int64), cat(2, t_cols, np.float64) if want_pred else None)
+            if out is not None:
+                for dst, src in zip(out, res):
+                    if dst is not None and src is not None:
+                        dst[:row] = src
+                res = tuple(None if (dst is None or src is None) else dst[:row] for dst, src in zip(out, res))
+            return res
         o_dist, o_idx, o_pred = out if out is not None else (None, None, None)
         pieces = []
         row = 0
+        stream = None
+        stream_dtype = None
         try:
-            with eng.open_stream(k, weights=weights, want_dist=return_distance,
-                                 deterministic=use_deterministic_ordering,
-                                 decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
-                                 apply_affine=apply_affine, check_finite=True) as stream:
-                for tile in tiles:
-                    if is_torch_cuda_tensor(tile):
-                        raise TypeError("streamed tiles are host arrays (they travel through the pinned "
-                                        "PCIe pipeline); pass CUDA tensors to kneighbors() / predict()")
-                    tile = validate(tile)
-                    n = tile.shape[0]
-                    if n == 0:
-                        continue
+            for tile in tiles:
+                if is_torch_cuda_tensor(tile):
+                    raise TypeError("streamed tiles are host arrays (they travel through the pinned "
+                                    "PCIe pipeline); pass CUDA tensors to kneighbors() / predict()")
+                tile = validate(tile)
+                n = tile.shape[0]
+                if n == 0:
+                    continue
+                if stream is None:
+                    # the element type of the first tile is the stream's (narrow rasters travel at their own width)
+                    code = eng.query_dtype_code(tile, self._formula())
+                    stream_dtype = tile.dtype if code else np.dtype(np.float64)
+                    stream = eng.open_stream(k, weights=weights, want_dist=return_distance,
+                                             deterministic=use_deterministic_ordering,
+                                             decimals=self.DISTANCE_PRECISION_DECIMALS, formula=self._formula(),
+                                             apply_affine=apply_affine, check_finite=True, query_dtype=code)
+                if tile.dtype != stream_dtype:
+                    if stream_dtype != np.float64:
+                        raise ValueError(f"the tiles of one streamed call must share an element type: got {tile.dtype} "
+                                         f"after {stream_dtype}")
+                    tile = np.ascontiguousarray(tile, dtype=np.float64)
 
-                    def window(arr, cols, dtype):
-                        if arr is None:
-                            return None
-                        w = arr[row:row + n]
-                        if w.shape != (n, cols) or w.dtype != dtype or not w.flags.c_contiguous:
-                            raise ValueError(f"out arrays must be C-contiguous, {np.dtype(dtype)}, with "
-                                             f"{cols} columns and at least {row + n} rows")
-                        return w
+                def window(arr, cols, dtype):
+                    if arr is None:
+                        return None
+                    w = arr[row:row + n]
+                    if w.shape != (n, cols) or w.dtype != dtype or not w.flags.c_contiguous:
+                        raise ValueError(f"out arrays must be C-contiguous, {np.dtype(dtype)}, with "
+                                         f"{cols} columns and at least {row + n} rows")
+                    return w
 
-                    got = stream.push(tile, out_idx=window(o_idx, k, np.int64),
-                                      out_dist=window(o_dist, k, np.float64) if return_distance else None,
-                                      out_pred=window(o_pred, t_cols, np.float64) if want_pred else None,
-                                      need_idx=not want_pred)
-                    if out is None:
-                        pieces.append(got)
-                    row += n
+                got = stream.push(tile, out_idx=window(o_idx, k, np.int64),
+                                  out_dist=window(o_dist, k, np.float64) if return_distance else None,
+                                  out_pred=window(o_pred, t_cols, np.float64) if want_pred else None,
+                                  need_idx=not want_pred)
+                if out is None:
+                    pieces.append(got)
+                row += n
+            if stream is not None:
+                done, stream = stream, None
+                done.close()
         except _native.HipBackendError as err:
             _reraise(err, owner if owner is not None else self)
+        finally:
+            if stream is not None:  # an error on the way: free the native stream without masking it
+                try:
+                    stream.close()
+                except _native.HipBackendError:
+                    pass
         if out is not None:
             trim = lambda a: None if a is None else a[:row]  # noqa: E731
             return trim(o_dist) if return_distance else None, trim(o_idx), trim(o_pred) if want_pred else None
@@ -501,7 +654,7 @@ class TransformedKNeighborsRegressor(BaseEstimator, ABC):
                                  f"{d_in} features as input.")
             return X
         # finiteness is tested on the device by the kernel that reads the rows (check_finite)
-        return validate_data(self.transformer_, X=X, reset=False, dtype=np.float64, order="C",
+        return validate_data(self.transformer_, X=X, reset=False, dtype=_QUERY_DTYPES, order="C",
                              ensure_all_finite=False)
 
     def kneighbors(self, X=None, n_neighbors=None, return_distance=True, return_dataframe_index=False,

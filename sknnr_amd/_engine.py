@@ -87,20 +87,29 @@ class KNNEngine:
 
     # ------------------------------------------------------------------------------------
     def _opts(self, k, *, exclude_self, deterministic, decimals, formula, apply_affine,
-              weight_mode=_native.WEIGHTS_UNIFORM, row_offset=0, check_finite=False):
+              weight_mode=_native.WEIGHTS_UNIFORM, row_offset=0, check_finite=False, query_dtype=0):
         return self._index.make_opts(
             k, exclude_self=exclude_self, deterministic=deterministic, decimals=decimals,
             formula={"direct": _native.FORMULA_DIRECT, "hamming": _native.FORMULA_HAMMING}.get(
                 formula, _native.FORMULA_EXPANDED),
             apply_affine=apply_affine, weight_mode=weight_mode, row_offset=row_offset,
-            check_finite=check_finite)
+            check_finite=check_finite, query_dtype=query_dtype)
 
-    def _as_device_rows(self, X, apply_affine):
-        """A float64, contiguous CUDA tensor on the engine's device with the expected columns."""
+    def query_dtype_code(self, X, formula="expanded") -> int:
+        """The sknnr_dtype under which the rows of ``X`` can be handed to the library as they are (float32, int16, uint16,
+        uint8, int32: widened by the kernel that reads them, exactly), or 0 = float64 (convert first): narrow rows need
+        the MFMA envelope (d <= 128) and a Euclidean formula."""
+        if X is None or formula == "hamming" or self.d > 128:
+            return 0
+        return _native.dtype_code(X.dtype) or 0
+
+    def _as_device_rows(self, X, apply_affine, query_dtype=0):
+        """A contiguous CUDA tensor on the engine's device with the expected columns: float64, or the narrower element
+        type ``query_dtype`` names (then left as it is)."""
         import torch
 
-        if X.dtype != torch.float64 or not X.is_contiguous():
-            X = X.to(torch.float64).contiguous()
+        if (query_dtype == 0 and X.dtype != torch.float64) or not X.is_contiguous():
+            X = (X if query_dtype else X.to(torch.float64)).contiguous()
         if X.device.index != self.device:
             raise ValueError(f"X is on cuda:{X.device.index}, the engine on cuda:{self.device}")
         self._check_columns(X, apply_affine)
@@ -120,10 +129,11 @@ class KNNEngine:
         into (torch.cuda input only), e.g. this rank's slot of an all-gather buffer.
         ``check_finite``: the kernels that read ``X`` also test it for NaN / infinity and the call
         raises ``HipBackendError(ERR_NONFINITE)`` (for CUDA tensors this synchronises the stream)."""
+        qdt = self.query_dtype_code(X, formula)
         opts = self._opts(k, exclude_self=exclude_self, deterministic=deterministic,
                           decimals=decimals, formula=formula,
                           apply_affine=apply_affine and X is not None, row_offset=row_offset,
-                          check_finite=check_finite and X is not None)
+                          check_finite=check_finite and X is not None, query_dtype=qdt)
         if X is None:
             if not exclude_self:
                 raise ValueError("X=None requires exclude_self=True")
@@ -132,7 +142,7 @@ class KNNEngine:
         if is_torch_cuda_tensor(X):
             import torch
 
-            X = self._as_device_rows(X, apply_affine)
+            X = self._as_device_rows(X, apply_affine, qdt)
             nq = X.shape[0]
             if out is not None:
                 dist, idx = out
@@ -157,7 +167,7 @@ class KNNEngine:
             return dist, idx
         if out is not None:
             raise ValueError("out= is only supported for torch.cuda inputs")
-        X = np.ascontiguousarray(X, dtype=np.float64)
+        X = np.ascontiguousarray(X) if qdt else np.ascontiguousarray(X, dtype=np.float64)
         self._check_columns(X, apply_affine)
         return self._index.kneighbors_host(X, opts, return_distance=return_distance)
 
@@ -190,16 +200,18 @@ class KNNEngine:
         if weights not in _WEIGHT_MODES:
             raise ValueError(f"weights not recognized: should be 'uniform', 'distance', or a callable; got {weights!r}")
         mode = _WEIGHT_MODES[weights]
+        qdt = self.query_dtype_code(X, formula)
         opts = self._opts(k, exclude_self=exclude_self, deterministic=deterministic, decimals=decimals,
                           formula=formula, apply_affine=apply_affine and X is not None,
-                          weight_mode=mode, row_offset=row_offset, check_finite=check_finite and X is not None)
+                          weight_mode=mode, row_offset=row_offset, check_finite=check_finite and X is not None,
+                          query_dtype=qdt)
         if X is None:
             nq = self.n_ref - row_offset if n_self_rows is None else int(n_self_rows)
             return self._index.predict_host(None, opts, nq=nq)
         if is_torch_cuda_tensor(X):
             import torch
 
-            X = self._as_device_rows(X, apply_affine)
+            X = self._as_device_rows(X, apply_affine, qdt)
             nq = X.shape[0]
             pred = torch.empty((nq, self.t), dtype=torch.float64, device=X.device)
             if nq:
@@ -208,7 +220,7 @@ class KNNEngine:
                 if check_finite:
                     self._index.check_finite(stream)
             return pred
-        X = np.ascontiguousarray(X, dtype=np.float64)
+        X = np.ascontiguousarray(X) if qdt else np.ascontiguousarray(X, dtype=np.float64)
         self._check_columns(X, apply_affine)
         return self._index.predict_host(X, opts)
 
@@ -262,7 +274,7 @@ class KNNEngine:
         return self._index.merge_shards_host(X, opts, shard_val, shard_idx, nq=nq)
 
     def open_stream(self, k, *, weights=None, want_dist=True, deterministic=True, decimals=10,
-                    formula="expanded", apply_affine=False, row_offset=0, check_finite=False):
+                    formula="expanded", apply_affine=False, row_offset=0, check_finite=False, query_dtype=0):
         """A :class:`sknnr_amd._native.QueryStream` over host tiles: ``push(tile)`` keeps the PCIe
         pipeline full across tiles and carries the global row offset.  ``weights`` (``"uniform"`` /
         ``"distance"``) also asks for predictions."""
@@ -272,8 +284,12 @@ class KNNEngine:
         opts = self._opts(k, exclude_self=False, deterministic=deterministic, decimals=decimals,
                           formula=formula, apply_affine=apply_affine,
                           weight_mode=_WEIGHT_MODES[weights] if want_pred else _native.WEIGHTS_UNIFORM,
-                          row_offset=row_offset, check_finite=check_finite)
+                          row_offset=row_offset, check_finite=check_finite, query_dtype=query_dtype)
         return self._index.open_stream(opts, want_dist=want_dist, want_pred=want_pred)
+
+    def hamming_distances(self, X, rows=None):
+        """Full weighted-Hamming distance rows of ``X[rows]`` (``X`` None: of the fitted rows) from the device."""
+        return self._index.hamming_distances_host(X, rows)
 
     def crosswalk(self, idx, table):
         """``table[idx]`` for int64 dataframe ids (REF _base.py:177-180)."""

@@ -31,7 +31,24 @@ ERR_UNSUPPORTED = -4
 ERR_HIP = -5
 ERR_NO_DEVICE = -6
 ERR_NONFINITE = -7
-ABI_VERSION = 4
+ABI_VERSION = 5
+
+# sknnr_dtype (include/sknnr_hip.h): query rows narrower than float64 are widened by the kernel that reads them
+DTYPE_CODES = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int16): 2, np.dtype(np.uint16): 3,
+               np.dtype(np.uint8): 4, np.dtype(np.int32): 5}
+
+
+def dtype_code(dt) -> int | None:
+    """The sknnr_dtype of a numpy / torch dtype, or None when the rows must be converted to float64 first."""
+    try:
+        return DTYPE_CODES.get(np.dtype(dt))
+    except TypeError:  # a torch dtype
+        name = str(dt).replace("torch.", "")
+        try:
+            return DTYPE_CODES.get(np.dtype(name))
+        except TypeError:
+            return None
+
 
 # every symbol include/sknnr_hip.h declares (checked by tests/test_cabi.py)
 EXPORTED_SYMBOLS = (
@@ -50,6 +67,7 @@ EXPORTED_SYMBOLS = (
     "sknnr_kneighbors",
     "sknnr_predict",
     "sknnr_predict_from_neighbors",
+    "sknnr_hamming_distances",
     "sknnr_shard_candidates",
     "sknnr_merge_shards",
     "sknnr_stream_begin",
@@ -71,6 +89,8 @@ class QueryOpts(ctypes.Structure):
         ("apply_affine", c_int32),
         ("weight_mode", c_int32),
         ("check_finite", c_int32),
+        ("query_dtype", c_int32),
+        ("reserved_", c_int32),
         ("row_offset", c_int64),
     ]
 
@@ -159,6 +179,7 @@ def load(build_if_missing: bool = False):
     lib.sknnr_predict.argtypes = [vp, vp, c_int64, POINTER(QueryOpts), vp, vp, vp, c_int32, vp]
     lib.sknnr_predict_from_neighbors.argtypes = [vp, vp, vp, vp, c_int64, c_int32, c_int32, vp,
                                                  c_int32, vp]
+    lib.sknnr_hamming_distances.argtypes = [vp, vp, c_int64, vp, c_int64, vp, c_int32, vp]
     lib.sknnr_shard_candidates.argtypes = [vp, vp, c_int64, POINTER(QueryOpts), c_int64, vp, vp, c_int32, vp]
     lib.sknnr_merge_shards.argtypes = [vp, vp, c_int64, POINTER(QueryOpts), c_int32, vp, vp, vp, vp, c_int32, vp]
     lib.sknnr_crosswalk.argtypes = [vp, c_int64, vp, c_int64, vp, c_int32, c_int32, vp]
@@ -183,6 +204,17 @@ def _host_ptr(a):
 
 def _c_f64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _c_rows(a, opts):
+    """Query rows as the call will read them: C-contiguous, of the element type ``opts.query_dtype`` names (the caller set
+    it from the array's dtype: Index.make_opts(query_dtype=...)), else float64."""
+    if a is None:
+        return None
+    for dt, code in DTYPE_CODES.items():
+        if code == opts.query_dtype:
+            return np.ascontiguousarray(a, dtype=dt)
+    raise ValueError(f"unknown query_dtype {opts.query_dtype}")
 
 
 class Index:
@@ -249,10 +281,10 @@ class Index:
     @staticmethod
     def make_opts(k, exclude_self=False, deterministic=True, decimals=10, formula=FORMULA_EXPANDED,
                   apply_affine=False, weight_mode=WEIGHTS_UNIFORM, row_offset=0,
-                  check_finite=False) -> QueryOpts:
+                  check_finite=False, query_dtype=0) -> QueryOpts:
         return QueryOpts(int(k), int(bool(exclude_self)), int(bool(deterministic)), int(decimals),
                          int(formula), int(bool(apply_affine)), int(weight_mode), int(bool(check_finite)),
-                         int(row_offset))
+                         int(query_dtype), 0, int(row_offset))
 
     def check_finite(self, stream=0) -> None:
         """Poll the non-finite-input flag of device-memory calls made with ``check_finite``
@@ -264,7 +296,7 @@ class Index:
 
     # ---- host (numpy) entry points --------------------------------------------------------
     def kneighbors_host(self, q, opts: QueryOpts, nq=None, return_distance=True):
-        q = _c_f64(q)
+        q = _c_rows(q, opts)
         if q is not None:
             nq = q.shape[0]
         k = opts.n_neighbors
@@ -275,7 +307,7 @@ class Index:
         return dist, idx
 
     def predict_host(self, q, opts: QueryOpts, nq=None, return_neighbors=False):
-        q = _c_f64(q)
+        q = _c_rows(q, opts)
         if q is not None:
             nq = q.shape[0]
         k = opts.n_neighbors
@@ -314,6 +346,18 @@ class Index:
         check(load().sknnr_predict_from_neighbors(
             self.handle, c_void_p(dist_ptr or None), c_void_p(idx_ptr), c_void_p(w_ptr or None), nq, k,
             int(weight_mode), c_void_p(pred_ptr), MEM_DEVICE, c_void_p(stream or None)))
+
+    def hamming_distances_host(self, q, rows=None):
+        """Full weighted-Hamming distance rows ``(len(rows), n_ref)`` of the query rows ``q[rows]`` (``q`` None: of the
+        index's own rows), computed on the device in the reference's float64 arithmetic (sknnr_hamming_distances)."""
+        q = _c_f64(q)
+        nq = self.n_ref if q is None else q.shape[0]
+        rows = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
+        n_rows = nq if rows is None else rows.size
+        out = np.empty((n_rows, self.n_ref), dtype=np.float64)
+        check(load().sknnr_hamming_distances(self.handle, _host_ptr(q), nq, _host_ptr(rows), n_rows, _host_ptr(out),
+                                             MEM_HOST, None))
+        return out
 
     # ---- reference-sharded search (include/sknnr_hip.h) -------------------------------------------
     def shard_candidates_host(self, q, opts: QueryOpts, index_offset=0):
@@ -370,6 +414,7 @@ class QueryStream:
         self._h = c_void_p()
         self._keep = []
         self.k = opts.n_neighbors
+        self._opts = opts
         self.want_dist, self.want_pred = bool(want_dist), bool(want_pred)
         check(load().sknnr_stream_begin(index.handle, byref(opts), int(self.want_dist), int(self.want_pred),
                                         byref(self._h)))
@@ -377,7 +422,7 @@ class QueryStream:
     def push(self, q, out_idx=None, out_dist=None, out_pred=None, need_idx=True):
         """Answer the rows of ``q``; returns the (idx, dist, pred) arrays that will hold the results
         (the ones passed in, or fresh ones; ``need_idx=False`` with predictions skips the indices)."""
-        q = _c_f64(q)
+        q = _c_rows(q, self._opts)
         nq = q.shape[0]
         if out_idx is None and (need_idx or not self.want_pred):
             out_idx = np.empty((nq, self.k), dtype=np.int64)

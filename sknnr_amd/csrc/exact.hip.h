@@ -28,8 +28,27 @@ namespace sknnr {
 // The block's rows are staged through LDS with coalesced reads (row stride odd ->
 // conflict-free ds_read_b64); proj/mu are wave-uniform -> scalar loads.
 // ---------------------------------------------------------------------------------------
+// Element types of the query rows (include/sknnr_hip.h, sknnr_dtype): widened to float64 by the load, exactly -- what the
+// reference's validate_data / float64 promotion does on the host (REF transformers/_cca_transformer.py:78-87).
+enum : int { kDtypeF64 = 0, kDtypeF32 = 1, kDtypeI16 = 2, kDtypeU16 = 3, kDtypeU8 = 4, kDtypeI32 = 5, kDtypeCount = 6 };
+__host__ __device__ constexpr int dtype_bytes(int dt) {
+    return dt == kDtypeF64 ? 8 : (dt == kDtypeF32 || dt == kDtypeI32 ? 4 : (dt == kDtypeU8 ? 1 : 2));
+}
+// element i of a typed array as float64 (dt is wave-uniform: a scalar branch)
+__device__ __forceinline__ double load_as_f64(const void* __restrict__ x, int dt, long i) {
+    switch (dt) {
+        case kDtypeF32: return (double)((const float*)x)[i];
+        case kDtypeI16: return (double)((const short*)x)[i];
+        case kDtypeU16: return (double)((const unsigned short*)x)[i];
+        case kDtypeU8: return (double)((const unsigned char*)x)[i];
+        case kDtypeI32: return (double)((const int*)x)[i];
+        default: return ((const double*)x)[i];
+    }
+}
+
 struct PrepArgs {
-    const double* x;       // (nq, d_in) query rows of this launch
+    const void* x;         // (nq, d_in) query rows of this launch, elements of x_dtype
+    int x_dtype;           // kDtype*: float64 unless the caller handed narrower rows
     long nq;               // live rows
     long nq_pad;           // rows of the fragment image to write (multiple of the block size)
     int d_in;              // columns of x
@@ -73,14 +92,14 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
     long n_here = a.nq - q0;
     n_here = n_here < 0 ? 0 : (n_here > BT ? BT : n_here);
     const long n_el = n_here * a.d_in;
-    const double* xsrc = a.x + q0 * a.d_in;
+    const long e0 = q0 * a.d_in;
     {
         // coalesced walk over the block's contiguous rows; (row, col) advanced incrementally
         int r = tid / a.d_in, c = tid - (tid / a.d_in) * a.d_in;
         const int dr = BT / a.d_in, dc = BT - dr * a.d_in;
         bool has_nan = false, has_inf = false;
         for (long e = tid; e < n_el; e += BT) {
-            double v = xsrc[e];
+            double v = load_as_f64(a.x, a.x_dtype, e0 + e);
             classify(v, has_nan, has_inf);
             if (a.center) v = v - a.center[c];
             if (a.scale) v = v / a.scale[c];
@@ -163,11 +182,11 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
     for (int j = 0; j < DP; ++j) acc[j] = 0.0;
     bool has_nan = false, has_inf = false;
     if (live) {
-        const double* xr = a.x + q * a.d_in;
+        const long xe = q * a.d_in;  // first element of the row
         if (a.proj) {
             int c = 0;
-            if ((a.d_in & 1) == 0) {
-                const double2* x2 = (const double2*)xr;
+            if ((a.d_in & 1) == 0 && a.x_dtype == kDtypeF64) {
+                const double2* x2 = (const double2*)((const double*)a.x + xe);
                 for (; c < a.d_in; c += 2) {
                     const double2 xv = x2[c >> 1];
                     double v0 = xv.x, v1 = xv.y;
@@ -183,7 +202,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
                 }
             }
             for (; c < a.d_in; ++c) {
-                double v = xr[c];
+                double v = load_as_f64(a.x, a.x_dtype, xe + c);
                 classify(v, has_nan, has_inf);
                 if (a.center) v = v - a.center[c];
                 if (a.scale) v = v / a.scale[c];
@@ -195,7 +214,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
 #pragma unroll
             for (int k = 0; k < DP; ++k) {
                 if (k < a.d) {
-                    double v = xr[k];
+                    double v = load_as_f64(a.x, a.x_dtype, xe + k);
                     classify(v, has_nan, has_inf);
                     if (a.center) v = v - a.center[k];
                     if (a.scale) v = v / a.scale[k];

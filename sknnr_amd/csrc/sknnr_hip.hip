@@ -1174,9 +1174,10 @@ namespace {
 
 // `cells`: also name every row's cell (query bucketing); *cells_done tells whether this kernel did (the
 // register-resident one does; otherwise the caller runs cell_assign_kernel on the transformed rows)
-int launch_prep(sknnr_index* ix, const double* x, long nq, long nq_pad, bool affine, double* xt,
-                hipStream_t st, bool check_finite = false, bool cells = false, bool* cells_done = nullptr) {
+int launch_prep(sknnr_index* ix, const void* x, long nq, long nq_pad, bool affine, double* xt,
+                hipStream_t st, bool check_finite = false, bool cells = false, bool* cells_done = nullptr, int x_dtype = kDtypeF64) {
     PrepArgs a{};
+    a.x_dtype = x_dtype;
     if (cells_done) *cells_done = false;
     a.status = check_finite ? ix->status.p : nullptr;
     a.x = x;
@@ -1386,9 +1387,15 @@ struct CallCtx {
     bool coarse;
 };
 
-int validate_call(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o, int64_t* out_idx) {
+int validate_call(sknnr_index* ix, const void* q, int64_t nq, const sknnr_query_opts* o, int64_t* out_idx) {
     if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
     if (!o) return fail(SKNNR_ERR_INVALID, "opts is NULL");
+    if (o->query_dtype < 0 || o->query_dtype >= kDtypeCount) return fail(SKNNR_ERR_INVALID, "unknown query_dtype %d", o->query_dtype);
+    if (o->query_dtype != SKNNR_DTYPE_F64 && q) {
+        // narrow rows are widened by the query preparation kernel, which exists inside the MFMA envelope only
+        if (ix->ks == 0) return fail(SKNNR_ERR_UNSUPPORTED, "query_dtype %d needs d <= 128 (d = %d): pass float64 rows", o->query_dtype, ix->d);
+        if (o->formula == SKNNR_FORMULA_HAMMING) return fail(SKNNR_ERR_UNSUPPORTED, "node ids are float64: query_dtype must be 0 with formula = HAMMING");
+    }
     if (nq < 0) return fail(SKNNR_ERR_INVALID, "nq must be >= 0");
     if (!out_idx && nq > 0) return fail(SKNNR_ERR_INVALID, "out_idx is NULL");
     if (o->n_neighbors <= 0) return fail(SKNNR_ERR_INVALID, "Expected n_neighbors > 0. Got %d", o->n_neighbors);
@@ -1425,11 +1432,15 @@ int validate_call(sknnr_index* ix, const double* q, int64_t nq, const sknnr_quer
 // Device-resident core: nq rows at xdev (raw if affine else transformed), outputs on device.
 // raw / id_offset: shard candidates (sknnr_shard_candidates): squared values ascending by (value, index), indices +
 // id_offset, no post-steps
-int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_opts* o, double* d_dist,
+int run_device(sknnr_index* ix, const void* xdev, long nq, const sknnr_query_opts* o, double* d_dist,
                long* d_idx, hipStream_t st, int raw = 0, long id_offset = 0) {
     const int kk = o->n_neighbors + (o->exclude_self ? 1 : 0);
     const bool affine = o->apply_affine != 0 && xdev != nullptr;
     const bool self_rows = xdev == nullptr;
+    // rows narrower than float64 (opts->query_dtype): the prep kernel widens them and writes the float64 rows everything
+    // after it reads (finaliser, exact scan), as it does for rows that go through the affine map
+    const int x_dtype = self_rows ? kDtypeF64 : o->query_dtype;
+    const bool to_xt = affine || x_dtype != kDtypeF64;
     const bool coarse = ix->ks > 0 && kk <= kCoarseMaxKK && o->formula != SKNNR_FORMULA_HAMMING;
     const int d_x = affine ? ix->d_in : ix->d;
     if (nq > 0x7fffffffL) return fail(SKNNR_ERR_UNSUPPORTED, "more than 2^31 - 1 query rows in one call");
@@ -1440,15 +1451,15 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     const bool check_finite = o->check_finite != 0 && xdev != nullptr;
 
     // transformed rows of the WHOLE call: the exact scan at the end reads any row of it
-    const double* xq_call = self_rows ? ix->ref64.p + o->row_offset * ix->d : xdev;
-    if (affine) {
+    const double* xq_call = self_rows ? ix->ref64.p + o->row_offset * ix->d : (const double*)xdev;
+    if (to_xt) {
         HIP_TRY(ix->xt.ensure((size_t)nq * ix->d));
         xq_call = ix->xt.p;
     }
     const long chunk = chunk_rows(ix->ks, coarse_list_len(ix, kk));
     const long cap = std::min(chunk, nq);
     const long cap_pad = (cap + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
-    if (coarse || affine) {
+    if (coarse || to_xt) {
         HIP_TRY(ix->qimg.ensure((size_t)(cap_pad / 32) * 2 * ix->ks * 64));
         HIP_TRY(ix->qnc.ensure(cap_pad));
     }
@@ -1498,19 +1509,21 @@ int run_device(sknnr_index* ix, const double* xdev, long nq, const sknnr_query_o
     ct.coarse_used = 0;
     ct.coarse_rows = 0;
     HIP_TRY(hipEventRecord(ct.e0, st));
-    if (check_finite && !(coarse || affine)) {
+    if (check_finite && !(coarse || to_xt)) {
         // no prep kernel reads the rows on this path: scan them here
         const long n_el = nq * (long)d_x;
-        HIP_TRY(launch::check_finite(xdev, n_el, ix->status.p, st));
+        HIP_TRY(launch::check_finite((const double*)xdev, n_el, ix->status.p, st));
     }
     for (long c0 = 0; c0 < nq; c0 += chunk) {
         const long n = std::min(chunk, nq - c0);
         const long n_pad = (n + kRowQuantum - 1) / kRowQuantum * kRowQuantum;
-        const double* xin = self_rows ? xq_call + c0 * ix->d : xdev + c0 * d_x;
+        const void* xin = self_rows ? (const void*)(xq_call + c0 * ix->d)
+                                    : (const void*)((const char*)xdev + (size_t)c0 * d_x * dtype_bytes(x_dtype));
         const bool bucketed = coarse && ix->cell_depth > 0 && use_coarse2(ix, coarse_list_len(ix, kk));
         bool cells_done = false;
-        if (coarse || affine) {
-            int rc = launch_prep(ix, xin, n, n_pad, affine, affine ? ix->xt.p + c0 * ix->d : nullptr, st, check_finite, bucketed, &cells_done);
+        if (coarse || to_xt) {
+            int rc = launch_prep(ix, xin, n, n_pad, affine, to_xt ? ix->xt.p + c0 * ix->d : nullptr, st, check_finite, bucketed, &cells_done,
+                                 x_dtype);
             if (rc) return rc;
         }
         if (!coarse) continue;
@@ -1758,6 +1771,7 @@ struct HostPipe {
     sknnr_query_opts o{};        // o.row_offset advances with every submitted tile
     bool want_dist = false, want_idx = true, want_pred = false;
     int k = 0, t = 0, d_x = 0;
+    size_t x_esz = sizeof(double);  // bytes per element of the caller's rows (opts->query_dtype)
     struct Pending {
         bool live = false;
         long n = 0;
@@ -1770,7 +1784,7 @@ struct HostPipe {
     // look-ahead copy-in (one-shot calls know their next tile): the job that stages tile `ahead_tile` into slot `ahead_slot`
     std::packaged_task<int()> deferred[kHostSlots];  // SKNNR_PIPE_WORKERS=0: the copy-out jobs, run when the slot is drained
     std::future<int> ahead_done;
-    const double* ahead_q = nullptr;
+    const void* ahead_q = nullptr;
     int ahead_slot = -1;
     int d2h_slot = -1;  // slot whose kernels are enqueued and whose device-to-host copies are not yet (pipe_enqueue_d2h)
     double ms_copy_in = 0, ms_copy_out = 0, ms_wait = 0, ms_enqueue = 0;  // host-thread time per phase (SKNNR_PIPE_TRACE=1)
@@ -1794,6 +1808,7 @@ int pipe_open(HostPipe& p, sknnr_index* ix, const sknnr_query_opts* o, bool want
     p.k = o->n_neighbors;
     p.t = ix->t;
     p.d_x = o->apply_affine ? ix->d_in : ix->d;
+    p.x_esz = (size_t)dtype_bytes(o->query_dtype);
     // (each object on its own: a creation that failed half way is completed by the next call, never skipped)
     for (hipStream_t* h : {&ix->st_h2d, &ix->st_run, &ix->st_d2h})
         if (!*h) HIP_TRY(hipStreamCreateWithFlags(h, hipStreamNonBlocking));
@@ -1833,11 +1848,12 @@ int pipe_prepare_slot(HostPipe& p, int b, long n) {
     int rc = pipe_drain(p, b);  // the slot's previous tile must have left before its buffers are reused
     if (rc) return rc;
     const int k = p.k, t = p.t, d_x = p.d_x;
-    if ((rc = ensure_pinned(sl.pin_x, sl.pin_x_n, (size_t)n * d_x))) return rc;
+    const size_t x_f64 = ((size_t)n * d_x * p.x_esz + 7) / 8;  // the tile's rows, in 8-byte units
+    if ((rc = ensure_pinned(sl.pin_x, sl.pin_x_n, x_f64))) return rc;
     if ((rc = ensure_pinned(sl.pin_i, sl.pin_i_n, (size_t)n * k))) return rc;
     if (p.want_dist && (rc = ensure_pinned(sl.pin_d, sl.pin_d_n, (size_t)n * k))) return rc;
     if (p.want_pred && (rc = ensure_pinned(sl.pin_p, sl.pin_p_n, (size_t)n * t))) return rc;
-    HIP_TRY(sl.dev_x.ensure((size_t)n * d_x));
+    HIP_TRY(sl.dev_x.ensure(x_f64));
     HIP_TRY(sl.dev_i.ensure((size_t)n * k));
     HIP_TRY(sl.dev_d.ensure((size_t)n * k));
     if (p.want_pred) HIP_TRY(sl.dev_p.ensure((size_t)n * t));
@@ -1897,7 +1913,7 @@ int pipe_enqueue_d2h(HostPipe& p) {
 // One tile of at most host_chunk_rows() rows.  `q` may be reused by the caller as soon as this returns.
 // q_next / n_next: the tile the same call will submit next (or null): its rows are staged into the next slot's pinned
 // buffer by the copy-in worker while this tile is enqueued and the caller waits for older results.
-int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, double* op, const double* q_next = nullptr,
+int pipe_submit(HostPipe& p, const void* q, long n, double* od, long* oi, double* op, const void* q_next = nullptr,
                 long n_next = 0) {
     sknnr_index* ix = p.ix;
     const int b = p.slot_of;
@@ -1912,11 +1928,11 @@ int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, doub
         if (rc) return rc;
     } else {
         if ((rc = pipe_prepare_slot(p, b, n))) return rc;
-        parallel_copy(sl.pin_x, q, (size_t)n * d_x * sizeof(double));
+        parallel_copy(sl.pin_x, q, (size_t)n * d_x * p.x_esz);
     }
     const double t_enq = now_ms();
     p.ms_copy_in += t_enq - t_in;
-    HIP_TRY(hipMemcpyAsync(sl.dev_x.p, sl.pin_x, (size_t)n * d_x * sizeof(double), hipMemcpyHostToDevice, ix->st_h2d));
+    HIP_TRY(hipMemcpyAsync(sl.dev_x.p, sl.pin_x, (size_t)n * d_x * p.x_esz, hipMemcpyHostToDevice, ix->st_h2d));
     HIP_TRY(hipEventRecord(sl.ev_h2d, ix->st_h2d));
     // the PREVIOUS tile's results travel behind this tile's rows, on the same stream (see pipe_enqueue_d2h)
     if ((rc = pipe_enqueue_d2h(p))) return rc;
@@ -1943,7 +1959,7 @@ int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, doub
         const int b2 = p.slot_of;
         if ((rc = pipe_prepare_slot(p, b2, n_next))) return rc;
         double* dst = ix->slot[b2].pin_x;
-        const size_t bytes = (size_t)n_next * d_x * sizeof(double);
+        const size_t bytes = (size_t)n_next * d_x * p.x_esz;
         p.ahead_done = ix->w_in->post([=]() -> int {
             parallel_copy(dst, q_next, bytes);
             return SKNNR_OK;
@@ -1957,7 +1973,9 @@ int pipe_submit(HostPipe& p, const double* q, long n, double* od, long* oi, doub
 // Submit `nq` rows in tiles of at most host_chunk_rows().  A pipeline that starts empty ramps up: the device waits for
 // the first tile's staging copy and host-to-device transfer (7 ms for a 1M-row tile) with nothing to do, so the first
 // tiles are an eighth, a quarter and a half of the regular size.
-int pipe_submit_rows(HostPipe& p, const double* q, long nq, double* od, long* oi, double* op) {
+int pipe_submit_rows(HostPipe& p, const void* q_, long nq, double* od, long* oi, double* op) {
+    const char* q = (const char*)q_;
+    const size_t row_bytes = (size_t)p.d_x * p.x_esz;
     const long cap = host_chunk_rows();
     bool idle = p.d2h_slot < 0;
     for (const auto& pd : p.pending) idle = idle && !pd.live;
@@ -1978,8 +1996,8 @@ int pipe_submit_rows(HostPipe& p, const double* q, long nq, double* od, long* oi
     for (size_t i = 0; i < cuts.size(); ++i) {
         const long c1 = cuts[i], n = c1 - c0;
         const long n_next = i + 1 < cuts.size() ? cuts[i + 1] - c1 : 0;
-        int rc = pipe_submit(p, q + c0 * p.d_x, n, od ? od + c0 * p.k : nullptr, oi ? oi + c0 * p.k : nullptr,
-                             op ? op + c0 * p.t : nullptr, n_next ? q + c1 * p.d_x : nullptr, n_next);
+        int rc = pipe_submit(p, q + c0 * row_bytes, n, od ? od + c0 * p.k : nullptr, oi ? oi + c0 * p.k : nullptr,
+                             op ? op + c0 * p.t : nullptr, n_next ? q + c1 * row_bytes : nullptr, n_next);
         if (rc) return rc;
         c0 = c1;
     }
@@ -2052,7 +2070,7 @@ struct Prefault {
     }
 };
 
-int run_host_pipeline(sknnr_index* ix, const double* q, long nq, const sknnr_query_opts* o, double* out_dist,
+int run_host_pipeline(sknnr_index* ix, const void* q, long nq, const sknnr_query_opts* o, double* out_dist,
                       long* out_idx, double* out_pred) {
     if (ix->stream_open) return fail(SKNNR_ERR_INVALID, "a query stream is open on this handle: end it first");
     HostPipe p;
@@ -2107,7 +2125,7 @@ int run_self_rows(sknnr_index* ix, long nq, const sknnr_query_opts* o, double* o
 // ----------------------------------------------------------------------------------------
 // kneighbors
 // ----------------------------------------------------------------------------------------
-extern "C" int sknnr_kneighbors(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o,
+extern "C" int sknnr_kneighbors(sknnr_index* ix, const void* q, int64_t nq, const sknnr_query_opts* o,
                                 double* out_dist, int64_t* out_idx, int32_t mem, void* stream) {
     int rc = validate_call(ix, q, nq, o, out_idx);
     if (rc) return rc;
@@ -2122,12 +2140,79 @@ extern "C" int sknnr_kneighbors(sknnr_index* ix, const double* q, int64_t nq, co
 
 
 // ----------------------------------------------------------------------------------------
+// full weighted-Hamming distance rows (the reference's own choice among exactly tied rows: np.argpartition on the host)
+// ----------------------------------------------------------------------------------------
+extern "C" int sknnr_hamming_distances(sknnr_index* ix, const double* q, int64_t nq, const int64_t* rows, int64_t n_rows,
+                                       double* out, int32_t mem, void* stream) {
+    if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
+    if (!ix->has_hw) return fail(SKNNR_ERR_INVALID, "sknnr_hamming_distances needs sknnr_index_set_hamming_weights first");
+    if (n_rows < 0 || nq < 0) return fail(SKNNR_ERR_INVALID, "negative row count");
+    if (n_rows == 0) return SKNNR_OK;
+    if (!out) return fail(SKNNR_ERR_INVALID, "out is NULL");
+    if (mem != SKNNR_MEM_DEVICE && mem != SKNNR_MEM_HOST) return fail(SKNNR_ERR_INVALID, "unknown memspace %d", mem);
+    const long n_src = q ? nq : ix->n_ref;  // rows that `rows` may name
+    if (!rows && n_rows > n_src) return fail(SKNNR_ERR_INVALID, "n_rows = %ld exceeds the %ld query rows", (long)n_rows, n_src);
+    std::lock_guard<std::mutex> lock(ix->mtx);
+    HIP_TRY(hipSetDevice(ix->device));
+    HammingRowsArgs a{};
+    a.refT = ix->refT.p;
+    a.d = ix->d;
+    a.n_ref = (int)ix->n_ref;
+    a.hw = ix->hw.p;
+    a.hw_sum = ix->hw_sum;
+    if (mem == SKNNR_MEM_DEVICE) {
+        a.xq = q ? q : ix->ref64.p;
+        a.rows = (const long*)rows;  // (device memory: the caller vouches for the values)
+        a.n_rows = n_rows;
+        a.out = out;
+        HIP_TRY(launch::hamming_distance_rows(a, (hipStream_t)stream));
+        return SKNNR_OK;
+    }
+    for (int64_t i = 0; rows && i < n_rows; ++i)
+        if (rows[i] < 0 || rows[i] >= n_src) return fail(SKNNR_ERR_INVALID, "rows[%ld] = %ld outside [0, %ld)", (long)i, (long)rows[i], n_src);
+    // host buffers: the selected rows only travel in, their distance rows out, at most ~256 MB of them at a time
+    const long per = std::max<long>(1, std::min<long>(n_rows, (256L << 20) / (8 * std::max<long>(1, ix->n_ref))));
+    DevBuf<double> dq, dout;
+    DevBuf<long> drows;
+    HIP_TRY(dout.ensure((size_t)per * ix->n_ref));
+    if (q) HIP_TRY(dq.ensure((size_t)per * ix->d));
+    else HIP_TRY(drows.ensure((size_t)per));
+    std::vector<double> gathered;
+    std::vector<long> sel;
+    for (long c0 = 0; c0 < n_rows; c0 += per) {
+        const long n = std::min<long>(per, n_rows - c0);
+        if (q) {
+            gathered.resize((size_t)n * ix->d);
+            for (long i = 0; i < n; ++i) {
+                const long r = rows ? rows[c0 + i] : c0 + i;
+                std::memcpy(&gathered[(size_t)i * ix->d], q + (size_t)r * ix->d, (size_t)ix->d * sizeof(double));
+            }
+            HIP_TRY(hipMemcpy(dq.p, gathered.data(), gathered.size() * sizeof(double), hipMemcpyHostToDevice));
+            a.xq = dq.p;
+            a.rows = nullptr;
+        } else {
+            sel.resize((size_t)n);
+            for (long i = 0; i < n; ++i) sel[(size_t)i] = rows ? rows[c0 + i] : c0 + i;
+            HIP_TRY(hipMemcpy(drows.p, sel.data(), (size_t)n * sizeof(long), hipMemcpyHostToDevice));
+            a.xq = ix->ref64.p;
+            a.rows = drows.p;
+        }
+        a.n_rows = n;
+        a.out = dout.p;
+        HIP_TRY(launch::hamming_distance_rows(a, nullptr));
+        HIP_TRY(hipMemcpy(out + (size_t)c0 * ix->n_ref, dout.p, (size_t)n * ix->n_ref * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return SKNNR_OK;
+}
+
+// ----------------------------------------------------------------------------------------
 // reference-sharded search: per-shard candidates, then the merge
 // ----------------------------------------------------------------------------------------
 extern "C" int sknnr_shard_candidates(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o,
                                       int64_t index_offset, double* out_val, int64_t* out_idx, int32_t mem, void* stream) {
     int rc = validate_call(ix, q, nq, o, out_idx);
     if (rc) return rc;
+    if (o->query_dtype != SKNNR_DTYPE_F64) return fail(SKNNR_ERR_UNSUPPORTED, "the sharded entry points take float64 rows (query_dtype = 0)");
     if (!q || o->exclude_self)
         return fail(SKNNR_ERR_INVALID, "shard candidates are searched for given rows: the caller adds the self slot (n_neighbors + 1) and the merge drops it");
     if (!out_val && nq > 0) return fail(SKNNR_ERR_INVALID, "out_val is NULL");
@@ -2240,6 +2325,7 @@ extern "C" int sknnr_merge_shards(sknnr_index* ix, const double* q, int64_t nq, 
                                   int32_t mem, void* stream) {
     int rc = validate_call(ix, q, nq, o, out_idx);
     if (rc) return rc;
+    if (o->query_dtype != SKNNR_DTYPE_F64) return fail(SKNNR_ERR_UNSUPPORTED, "the sharded entry points take float64 rows (query_dtype = 0)");
     if (n_shards < 1 || n_shards > 64) return fail(SKNNR_ERR_INVALID, "n_shards must be in [1, 64], got %d", n_shards);
     if ((!shard_val || !shard_idx) && nq > 0) return fail(SKNNR_ERR_INVALID, "shard candidate arrays are NULL");
     const int kk = o->n_neighbors + (o->exclude_self ? 1 : 0);
@@ -2331,7 +2417,7 @@ extern "C" int sknnr_predict_from_neighbors(sknnr_index* ix, const double* dist,
     return SKNNR_OK;
 }
 
-extern "C" int sknnr_predict(sknnr_index* ix, const double* q, int64_t nq, const sknnr_query_opts* o, double* out_pred,
+extern "C" int sknnr_predict(sknnr_index* ix, const void* q, int64_t nq, const sknnr_query_opts* o, double* out_pred,
                              double* out_dist, int64_t* out_idx, int32_t mem, void* stream) {
     if (!ix) return fail(SKNNR_ERR_INVALID, "index is NULL");
     if (ix->t < 1) return fail(SKNNR_ERR_NO_TARGETS, "the index was created without targets");
@@ -2411,7 +2497,7 @@ extern "C" int sknnr_stream_begin(sknnr_index* ix, const sknnr_query_opts* o, in
     return SKNNR_OK;
 }
 
-extern "C" int sknnr_stream_push(sknnr_stream* s, const double* q, int64_t nq, double* out_dist, int64_t* out_idx,
+extern "C" int sknnr_stream_push(sknnr_stream* s, const void* q, int64_t nq, double* out_dist, int64_t* out_idx,
                                  double* out_pred) {
     if (!s) return fail(SKNNR_ERR_INVALID, "stream is NULL");
     if (nq < 0) return fail(SKNNR_ERR_INVALID, "nq must be >= 0");

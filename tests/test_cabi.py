@@ -52,14 +52,26 @@ def test_no_other_symbols_leak(native):
 
 def test_abi_version_and_last_error(native):
     lib = native.load()
-    assert lib.sknnr_abi_version() == native.ABI_VERSION == 4
+    assert lib.sknnr_abi_version() == native.ABI_VERSION == 5
     assert isinstance(lib.sknnr_last_error(), bytes)
 
 
 def test_struct_layouts_match_the_header(native):
-    assert ctypes.sizeof(native.QueryOpts) == 40
-    assert native.QueryOpts.row_offset.offset == 32
+    assert ctypes.sizeof(native.QueryOpts) == 48  # ABI v5: + query_dtype, reserved_
+    assert native.QueryOpts.row_offset.offset == 40
     assert native.QueryOpts.check_finite.offset == 28
+    assert native.QueryOpts.query_dtype.offset == 32
+    # the header's struct, compiled: same size and offsets
+    import subprocess, tempfile
+
+    src = '#include <stddef.h>\n#include <stdio.h>\n#include "sknnr_hip.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(sknnr_query_opts), offsetof(sknnr_query_opts, query_dtype), offsetof(sknnr_query_opts, row_offset), sizeof(sknnr_stats));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "layout.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "layout")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        got = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(v) for v in got] == [48, 32, 40, 88]
     assert ctypes.sizeof(native.Stats) == 88  # ABI v4: + mfma_executed_ratio
     assert native.Stats.total_kernel_ms.offset == 48
 
@@ -73,6 +85,7 @@ def test_argument_errors_without_touching_a_device(native):
     assert lib.sknnr_stream_begin(None, None, 0, 0, ctypes.byref(ctypes.c_void_p())) == native.ERR_INVALID
     assert lib.sknnr_stream_push(None, None, 1, None, None, None) == native.ERR_INVALID
     assert lib.sknnr_stream_flush(None) == native.ERR_INVALID
+    assert lib.sknnr_hamming_distances(None, None, 0, None, 1, None, 0, None) == native.ERR_INVALID
     assert lib.sknnr_stream_end(None, None) == 0  # NULL is allowed
     lib.sknnr_index_destroy(None)  # NULL is allowed
 

@@ -207,6 +207,119 @@ def test_estimators_with_mixed_type_forests(which, reference, atol, moscow_frame
         assert r2_score(f["y_train"].to_numpy(), patched) == pytest.approx(float(rf["score"]), rel=1e-5, abs=1e-8)
 
 
+@pytest.mark.parametrize("which, cls_name", [("randomForest", "RFNNRegressor"), ("gbnn", "GBNNRegressor")])
+def test_reference_regression_files_exact_under_the_numpy_tie_policy(which, cls_name, moscow_frames):
+    """hamming_tie_policy("numpy") -- the reference's own choice among exactly tied rows (np.argpartition on the full
+    distance row, which the device supplies): the reference maintainers' committed regression files for RFNN / GBNN
+    (REF tests/test_regressions.py:57-122, the files under REF tests/test_regressions/) are matched with
+    assert_array_equal on EVERY row, tie rows included -- neighbour indices, dataframe ids, predictions and score."""
+    import sknnr_amd
+
+    f = moscow_frames
+
+    def ref(stem):
+        return np.load(os.path.join(REF_DIR, f"{stem}_full_{which}_k5_.npz"))
+
+    with sknnr_amd.hamming_tie_policy("numpy"):
+        est = getattr(sknnr_amd, cls_name)(n_neighbors=5, random_state=42).fit(f["X_train"], f["y_train"])
+        est_w = getattr(sknnr_amd, cls_name)(n_neighbors=5, random_state=42, weights=yaimpute_weights).fit(f["X_train"], f["y_train"])
+        for kind, X in (("target", f["X_test"]), ("reference", None)):
+            for ret_ids, tag in ((False, "index"), (True, "ids")):
+                rf = np.load(os.path.join(REF_DIR, f"test_kneighbors_{kind}_full_{which}_k5_{tag}_.npz"))
+                dist, nn = est.kneighbors(X, return_dataframe_index=ret_ids)
+                np.testing.assert_array_equal(nn, rf["nn"])
+                np.testing.assert_allclose(dist, rf["dist"], rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(est.predict(X) if X is not None else est.independent_prediction_,
+                                       ref(f"test_predict_{kind}_unweighted")["pred"], rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(est_w.predict(X) if X is not None else est_w.independent_prediction_,
+                                       ref(f"test_predict_{kind}_weighted")["pred"], rtol=1e-5, atol=1e-8)
+        assert est.independent_score_ == pytest.approx(float(ref("test_predict_reference_unweighted")["score"]), rel=1e-6)
+        assert est_w.independent_score_ == pytest.approx(float(ref("test_predict_reference_weighted")["score"]), rel=1e-6)
+        # without the deterministic reorder the ORDER among tied rows is argpartition's as well: the oracle of that is
+        # scikit-learn's own brute Hamming search (the call the reference makes) on the node ids
+        from sklearn.neighbors import KNeighborsRegressor
+
+        ids_tr, ids_te = est.transformer_.transform(f["X_train"]), est.transformer_.transform(f["X_test"])
+        skl = KNeighborsRegressor(n_neighbors=5, algorithm="brute", metric="hamming",
+                                  metric_params={"w": est.hamming_weights_}).fit(ids_tr, f["y_train"])
+        for X, ids in ((f["X_test"], ids_te), (None, None)):
+            d_, i_ = est.kneighbors(X, use_deterministic_ordering=False)
+            sd, si = skl.kneighbors(ids)
+            np.testing.assert_array_equal(i_, si)
+            np.testing.assert_array_equal(d_, sd)
+        assert est.regressor_._last_numpy_tie_rows >= 0
+    # the default policy is back: lowest index first
+    assert sknnr_amd.get_hamming_tie_policy() == "lowest_index"
+
+
+@pytest.mark.parametrize("which, reference", [("randomForest", True), ("randomForest", False), ("gbnn", True), ("gbnn", False)])
+def test_mixed_type_forest_files_exact_under_the_numpy_tie_policy(which, reference, moscow_frames):
+    """REF tests/test_regressions.py:125-195 under hamming_tie_policy("numpy"): every row of the reference's four files,
+    no tie-class allowance (the mixed RFNN has 100 uniformly weighted trees: 12 / 5 boundary-tie rows)."""
+    import sknnr_amd
+
+    f = moscow_frames
+    cls = {"randomForest": sknnr_amd.RFNNRegressor, "gbnn": sknnr_amd.GBNNRegressor}[which]
+    rf = np.load(os.path.join(REF_DIR, f"test_estimators_with_mixed_type_forests_{'reference' if reference else 'target'}_{which}_.npz"))
+    with sknnr_amd.hamming_tie_policy("numpy"):
+        est = cls(n_neighbors=5, random_state=42).fit(f["X_train"], f["y_train"], y_fit=mixed_forest_y_fit(f["y_train"]))
+        if reference:
+            dist, nn = est.kneighbors()
+            pred = est.independent_prediction_
+        else:
+            dist, nn = est.kneighbors(f["X_test"])
+            pred = est.predict(f["X_test"])
+    np.testing.assert_array_equal(nn, rf["nn"])
+    np.testing.assert_allclose(dist, rf["dist"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(pred, rf["pred"], rtol=1e-5, atol=1e-8)
+    if reference:
+        assert est.independent_score_ == pytest.approx(float(rf["score"]), rel=1e-5, abs=1e-8)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_reference_generated_goldens_exact_under_the_numpy_tie_policy(name, N):
+    """The fixtures generated by importing the reference (tests/golden/make_golden.py: 1,750 / 3,500 / 700 / 1,050 trees):
+    indices equal on every row under the numpy policy, through the raw regressor on the reference's node ids."""
+    import sknnr_amd
+
+    g = load_golden(f"moscow_{name}.npz")
+    ids_tr, ids_te, w = g["ids_train"].astype(np.float64), g["ids_test"].astype(np.float64), g["hamming_weights"]
+    with sknnr_amd.hamming_tie_policy("numpy"):
+        reg = sknnr_amd.RawKNNRegressor(n_neighbors=5, algorithm="brute", metric="hamming", metric_params={"w": w})
+        reg.fit(ids_tr, np.zeros((len(ids_tr), 1)))
+        d, i = reg.kneighbors(ids_te)
+        np.testing.assert_array_equal(i, g["kn_tgt_k5_nn"])
+        np.testing.assert_allclose(d, g["kn_tgt_k5_dist"], rtol=1e-12)
+        d, i = reg.kneighbors()
+        np.testing.assert_array_equal(i, g["kn_ref_k5_nn"])
+        np.testing.assert_allclose(d, g["kn_ref_k5_dist"], rtol=1e-12)
+        d, i = reg.kneighbors(ids_te, n_neighbors=1)
+        np.testing.assert_array_equal(i, g["kn_tgt_k1_nn"])
+        # tiles of a streamed call go through the same replay, positions carried from tile to tile
+        d_s, i_s = reg.kneighbors_chunks(iter([ids_te[:10], ids_te[10:11], ids_te[11:]]))
+        np.testing.assert_array_equal(i_s, g["kn_tgt_k5_nn"])
+
+
+def test_hamming_distance_rows_equal_scipy(N):
+    """sknnr_hamming_distances: full float64 distance rows of selected queries, bit-equal to scipy's cdist (the matrix
+    the reference's brute search materialises), for given rows and for the index's own rows."""
+    from scipy.spatial.distance import cdist
+
+    rng = np.random.default_rng(3)
+    ref = rng.integers(0, 9, (777, 37)).astype(np.float64)
+    q = rng.integers(0, 9, (100, 37)).astype(np.float64)
+    w = rng.random(37) + 0.01
+    ix = N.Index(ref)
+    ix.set_hamming_weights(w)
+    rows = np.array([5, 0, 99, 5, 42], dtype=np.int64)
+    np.testing.assert_array_equal(ix.hamming_distances_host(q, rows), cdist(q[rows], ref, "hamming", w=w))
+    np.testing.assert_array_equal(ix.hamming_distances_host(None, rows), cdist(ref[rows], ref, "hamming", w=w))
+    np.testing.assert_array_equal(ix.hamming_distances_host(q), cdist(q, ref, "hamming", w=w))
+    with pytest.raises(N.HipBackendError, match="outside"):
+        ix.hamming_distances_host(q, np.array([100], dtype=np.int64))
+    ix.close()
+
+
 def test_gbnn_on_synthetic_rows_matches_the_reference(N, O):
     """The reference's GBNN on 1,200 x 8 synthetic rows (real-valued train-improvement weights): its
     node ids / weights through the HIP search, its predictions from the HIP neighbours."""

@@ -234,3 +234,44 @@ def test_bench_starts_its_own_ranks():
     launch_at, torch_at = src.index("self_launch(args, argv)"), src.index("    import torch\n")
     assert launch_at < torch_at, "the parent must start its ranks before it imports torch / touches the GPU"
     assert "os.exec" not in src
+
+
+@pytest.mark.parametrize("deterministic", [True, False])
+@pytest.mark.parametrize("self_query", [False, True])
+def test_numpy_tie_replay_equals_scikit_learns_brute_hamming_search(deterministic, self_query):
+    """hamming_tie_policy("numpy"): the host-side replay of the reference's selection (argpartition, argsort, X=None
+    self removal, sknnr's reorder) on full distance rows gives what scikit-learn's brute Hamming search -- the call the
+    reference makes, REF _weighted_trees.py:53-59 -> SKL/neighbors/_base.py:733-760, :936-963 -- followed by
+    REF _base.py:166-175 gives, on inputs where nearly every row has exact ties (three node ids, integer weights)."""
+    from scipy.spatial.distance import cdist
+    from sklearn.neighbors import KNeighborsRegressor
+
+    from sknnr_amd._base import replay_reference_selection
+
+    rng = np.random.default_rng(5)
+    ref = rng.integers(0, 3, (300, 14)).astype(np.float64)
+    ref[40:48] = ref[7]  # more duplicates of a row than neighbours asked for (the dup_gr_nbrs corner of the X=None path)
+    q = rng.integers(0, 3, (80, 14)).astype(np.float64)
+    w = rng.integers(1, 4, 14).astype(np.float64)
+    for k in (1, 5, 9):
+        skl = KNeighborsRegressor(n_neighbors=k, algorithm="brute", metric="hamming", metric_params={"w": w}).fit(ref, np.zeros(300))
+        d, i = skl.kneighbors(None if self_query else q)
+        if deterministic:  # REF src/sknnr/_base.py:166-175
+            rounded = np.round(d / np.maximum(d.max(axis=1, keepdims=True), 1.0), decimals=10)
+            order = np.lexsort((i, np.abs(i - np.arange(len(i))[:, None]), rounded), axis=1)
+            d, i = np.take_along_axis(d, order, axis=1), np.take_along_axis(i, order, axis=1)
+        full = cdist(ref if self_query else q, ref, "hamming", w=w)
+        gd, gi = replay_reference_selection(full, k + self_query, np.arange(len(full)), self_query, deterministic, 10)
+        np.testing.assert_array_equal(gi, i)
+        np.testing.assert_array_equal(gd, d)
+
+
+def test_hamming_tie_policy_setting():
+    import sknnr_amd
+
+    assert sknnr_amd.get_hamming_tie_policy() == "lowest_index"
+    with sknnr_amd.hamming_tie_policy("numpy"):
+        assert sknnr_amd.get_hamming_tie_policy() == "numpy"
+    assert sknnr_amd.get_hamming_tie_policy() == "lowest_index"
+    with pytest.raises(ValueError, match="must be one of"):
+        sknnr_amd.set_hamming_tie_policy("scalar")
