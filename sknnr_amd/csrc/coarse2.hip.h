@@ -77,6 +77,9 @@ __host__ __device__ constexpr int seed_tiles_for(long n_tiles, int tps) {
 #ifndef SKNNR_V2_PAIR_FLUSH
 #define SKNNR_V2_PAIR_FLUSH 1  // the flush walks the entries of the two lanes of a query as one sequence, two per trip
 #endif
+#ifndef SKNNR_V2_WAVE_FLUSH
+#define SKNNR_V2_WAVE_FLUSH 1  // round 4: the queued entries of the whole wave are compacted and corrected 32 per trip
+#endif
 constexpr int kCoarse2Waves = SKNNR_V2_WAVES;
 constexpr int kCoarse2Nqb = 2;
 constexpr int kQueueCap = 5;      // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
@@ -287,9 +290,11 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         // The flush needs the lo fragments of this lane's column again and again: they are copied once into
         // fragment order by position (this wave's own 1-KiB blocks, written and later read by the same lanes), so that
         // every later fetch is one coalesced 1-KiB load instead of 64 pieces out of 32 rows' lines.
+        if constexpr (!SKNNR_V2_WAVE_FLUSH) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-            qlo[((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane] = __builtin_bit_cast(uint4, qfrag(r, 1, s));
+            for (int s = 0; s < KS; ++s)
+                qlo[((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane] = __builtin_bit_cast(uint4, qfrag(r, 1, s));
+        }
     }
 
 #ifdef SKNNR_V2_BL_RESIDENT  // experiment: the queries' lo fragments stay in registers (12-wave geometry: 168 VGPRs)
@@ -350,6 +355,113 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[qb][s], acc, 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- wave flush (round 4): the entries of ALL lanes compacted, corrected 32 per trip, then inserted by their owners ----
+    // The pair flush below corrects the entries of a query's two lanes two per trip: a flush is triggered by ONE lane holding
+    // kQueueFlushAt entries while the wave holds ~22 on 64 lanes, so it takes 2-3 trips of two dependent L2 round trips each
+    // with 8-11 lanes at work (8,800 wave-cycles per flush, profiles/r03_coarse_timers.txt).  Here every lane first moves its
+    // entries to consecutive slots of the queue region (prefix sum of the counts; DS operations of a wave execute in order:
+    // all reads are done before the first write), tagged with the query column; then lane pair p (lanes p, p + 32: the two
+    // K halves) corrects entry 32 t + p whatever column it belongs to -- the column's hi / lo fragments come from the row's
+    // own cache line of the query image, the row's fragments from the reference image, ALL of it one round of independent
+    // loads -- and writes the corrected value back; finally every lane walks its own entries (now corrected) into its list.
+    // The corrected value is the same expression as in the pair flush (main + (lo.hi + hi.lo over K half 0 + K half 1));
+    // which list an entry goes to does not matter to the certificate.  One L2 round trip per 32 entries instead of four to six.
+    auto flush_wave = [&](int qb) {
+        TSTAMP(1);
+        CTR(6, 1);
+        const unsigned qbase = qwave - (unsigned)lane * 8u + (unsigned)qb * (kQueueCap * 512u);  // this q-block's region (2,560 B)
+        const int c = cnt[qb];
+        // exclusive prefix sum of the counts (0 .. kQueueCap < 8: three ballots)
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64((c & 1) != 0), b1 = __builtin_amdgcn_ballot_w64((c & 2) != 0),
+                                 b2 = __builtin_amdgcn_ballot_w64((c & 4) != 0);
+        auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+        const int off = below(b0) + 2 * below(b1) + 4 * below(b2);
+        const int total = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
+        // (reads and their wait in ONE statement: nothing may touch the destination registers while the data is in flight)
+        static_assert(kQueueCap == 5, "five entries per lane are read here");
+        unsigned long long own[kQueueCap];
+        asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:512\n\tds_read_b64 %2, %5 offset:1024\n\t"
+                     "ds_read_b64 %3, %5 offset:1536\n\tds_read_b64 %4, %5 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(own[0]), "=&v"(own[1]), "=&v"(own[2]), "=&v"(own[3]), "=&v"(own[4])
+                     : "v"(qbase + (unsigned)lane * 8u)
+                     : "memory");
+#pragma unroll
+        for (int j = 0; j < kQueueCap; ++j) {
+            // (pos < 2^26: the image is addressed with 32-bit offsets, use_coarse2) -- the column rides in the top bits
+            const unsigned long long e = own[j] | ((unsigned long long)(unsigned)(lane & 31) << 58);
+            if (j < c) asm volatile("ds_write_b64 %0, %1" ::"v"(qbase + (unsigned)(off + j) * 8u), "v"(e) : "memory");
+        }
+        const unsigned qrow_base = qrow_lds - (unsigned)lane * 4u + (unsigned)qb * 256u;
+        for (int t0 = 0; t0 < total; t0 += 32) {
+            CTR(7, 1);
+            const int gi = t0 + (lane & 31);
+            const bool on = gi < total;
+            unsigned long long e;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(e) : "v"(qbase + (unsigned)(on ? gi : 0) * 8u) : "memory");
+            CTR(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(on)));
+            const unsigned hi32 = (unsigned)(e >> 32);
+            const int pos = (int)(hi32 & 0x03ffffffu), col = (int)(hi32 >> 26);
+            int r;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(qrow_base + (unsigned)col * 4u) : "memory");
+            const unsigned row = (unsigned)(pos & 31) * 16u + (unsigned)(32 * half) * 16u;
+            const unsigned oh = (unsigned)(pos >> 5) * (unsigned)TB + row;
+            const unsigned ol = (unsigned)(pos >> 5) * (unsigned)(KS * 1024) + row;
+            half8 fl[KS], fh[KS], qh[KS], ql[KS];
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                fl[s2] = *(const half8*)(rlo + ol + s2 * 1024);
+                fh[s2] = *(const half8*)(rhi + oh + s2 * 1024);
+                qh[s2] = qfrag(r, 0, s2);
+                ql[s2] = qfrag(r, 1, s2);
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                acc = dot8(fl[s2], qh[s2], acc);
+                acc = dot8(fh[s2], ql[s2], acc);
+            }
+            const float other = __shfl_xor(acc, 32, 64);
+            const float cv = __uint_as_float((unsigned)e) + (half ? other + acc : acc + other);  // K half 0 + K half 1
+            if (on && half == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(qbase + (unsigned)gi * 8u), "v"(cv) : "memory");
+        }
+        // every lane's own entries, corrected: into its list
+        for (int j = 0; __builtin_amdgcn_ballot_w64(j < c) != 0; ++j) {
+            const bool on = j < c;
+            unsigned long long e;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(e) : "v"(qbase + (unsigned)(on ? off + j : 0) * 8u) : "memory");
+            const float cv = __uint_as_float((unsigned)e);
+            const int pos = (int)((unsigned)(e >> 32) & 0x03ffffffu);
+            if constexpr (E == 0) {
+                if (on && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, pos);
+            } else {
+                // pooled lists (pair_union_rank): what this list lets go of is handed to the partner's at once, unless it is no
+                // smaller than `loose` (which stays above the query's final threshold)
+                float out_v = FLT_MAX;
+                int out_i = -1;
+                if (on) {
+                    if (cv < vals[qb][M - 1]) {
+                        out_v = vals[qb][M - 1];
+                        out_i = idxs[qb][M - 1];
+                        list_insert<M>(vals[qb], idxs[qb], cv, pos);
+                    } else {
+                        out_v = cv;
+                        out_i = pos;
+                    }
+                }
+                const bool offer = out_v < loose[qb];
+                if (__builtin_amdgcn_ballot_w64(offer) != 0) {
+                    const float in_v = __shfl_xor(offer ? out_v : FLT_MAX, 32, 64);
+                    const int in_i = __shfl_xor(out_i, 32, 64);
+                    if (in_v < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], in_v, in_i);
+                }
+            }
+        }
+        cnt[qb] = 0;
+        const float tight = pair_union_rank<M, E>(vals[qb]) + margin[qb];
+        loose[qb] = loose[qb] != loose[qb] ? loose[qb] : min2f(loose[qb], tight);  // (NaN = poisoned: stays)
+        TSTAMP(2);
     };
 
     // ---- flush: correct every queued entry, insert, tighten the pair's threshold ---------------------------
@@ -550,8 +662,12 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
             }
         }
         if (want > kQueueCap) loose[qb] = __builtin_nanf("");
-        if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) flush(qb);
-        else TSTAMP(1);  // visit scan without a flush
+        if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) {
+            if constexpr (SKNNR_V2_WAVE_FLUSH) flush_wave(qb);
+            else flush(qb);
+        } else {
+            TSTAMP(1);  // visit scan without a flush
+        }
     };
 
     // ---- seeding: a valid starting threshold from the first kSeedTiles tiles ------------------------------
@@ -639,7 +755,8 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
     TSTAMP(0);
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-        flush(qb);
+        if constexpr (SKNNR_V2_WAVE_FLUSH) flush_wave(qb);
+        else flush(qb);
         const size_t q = (size_t)qrow_of(qb);
         const size_t base = (q * 2 + half) * M;
         // a poisoned query (dropped hits) must fail the certificate: a NaN bound never certifies

@@ -1299,7 +1299,9 @@ bool use_coarse2(const sknnr_index* ix, int m_list) {
     // threshold the first tiles give every lane more hits per unit than its queue holds)
     // (and the flush addresses the image with 32-bit offsets)
     const long tiles2 = (long)ix->n_stages2 * tiles_per_stage2(ix->ks);
-    return enabled && tiles2 >= 2 * kSeedTiles && tiles2 * tile2_bytes(ix->ks) < (1L << 32) && coarse2_supported(ix->ks, m_list);
+    // (... and its flush tags a queued entry's image position, below 2^26, with the query column)
+    return enabled && tiles2 >= 2 * kSeedTiles && tiles2 * tile2_bytes(ix->ks) < (1L << 32) && tiles2 * 32 < (1L << 26) &&
+           coarse2_supported(ix->ks, m_list);
 }
 
 // List length per lane for kk neighbours searched: at least one spare slot keeps the certificate

@@ -252,10 +252,13 @@ def test_reference_regression_files_exact_under_the_numpy_tie_policy(which, cls_
     assert sknnr_amd.get_hamming_tie_policy() == "lowest_index"
 
 
-@pytest.mark.parametrize("which, reference", [("randomForest", True), ("randomForest", False), ("gbnn", True), ("gbnn", False)])
-def test_mixed_type_forest_files_exact_under_the_numpy_tie_policy(which, reference, moscow_frames):
+@pytest.mark.parametrize("which, reference, atol", [("randomForest", True, 1e-8), ("randomForest", False, 1e-8),
+                                                     ("gbnn", True, 1e-8), ("gbnn", False, 1e-2)])
+def test_mixed_type_forest_files_exact_under_the_numpy_tie_policy(which, reference, atol, moscow_frames):
     """REF tests/test_regressions.py:125-195 under hamming_tie_policy("numpy"): every row of the reference's four files,
-    no tie-class allowance (the mixed RFNN has 100 uniformly weighted trees: 12 / 5 boundary-tie rows)."""
+    no tie-class allowance (the mixed RFNN has 100 uniformly weighted trees: 12 / 5 boundary-tie rows); the distance
+    tolerances are the reference's own (its target-GBNN case allows 1e-2: "the tree weights are less accurate when using a
+    multi-class classification forest")."""
     import sknnr_amd
 
     f = moscow_frames
@@ -270,7 +273,7 @@ def test_mixed_type_forest_files_exact_under_the_numpy_tie_policy(which, referen
             dist, nn = est.kneighbors(f["X_test"])
             pred = est.predict(f["X_test"])
     np.testing.assert_array_equal(nn, rf["nn"])
-    np.testing.assert_allclose(dist, rf["dist"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(dist, rf["dist"], rtol=1e-5, atol=atol)
     np.testing.assert_allclose(pred, rf["pred"], rtol=1e-5, atol=1e-8)
     if reference:
         assert est.independent_score_ == pytest.approx(float(rf["score"]), rel=1e-5, abs=1e-8)

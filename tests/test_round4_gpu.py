@@ -88,8 +88,16 @@ def test_narrow_rows_outside_the_envelope_are_refused_by_the_library_and_widened
     ix = N.Index(ref)
     with pytest.raises(N.HipBackendError, match="needs d <= 128"):
         ix.kneighbors_host(q, ix.make_opts(3, query_dtype=N.dtype_code(np.float32)))
-    with pytest.raises(N.HipBackendError, match="unknown query_dtype"):
+    with pytest.raises(ValueError, match="unknown query_dtype"):  # (the binding refuses before the library would)
         ix.kneighbors_host(q.astype(np.float64), ix.make_opts(3, query_dtype=17))
+    import ctypes
+
+    o = ix.make_opts(3, query_dtype=17)
+    q64 = np.ascontiguousarray(q, dtype=np.float64)
+    out_i = np.empty((50, 3), dtype=np.int64)
+    rc = N.load().sknnr_kneighbors(ix.handle, q64.ctypes.data_as(ctypes.c_void_p), 50, ctypes.byref(o), None,
+                                   out_i.ctypes.data_as(ctypes.c_void_p), N.MEM_HOST, None)
+    assert rc == N.ERR_INVALID and b"unknown query_dtype" in N.load().sknnr_last_error()
     ix.close()
     est = sknnr_amd.RawKNNRegressor(n_neighbors=3).fit(ref, ref[:, :2])  # d > 128: exact scan only, float64 rows
     d0, i0 = est.kneighbors(q.astype(np.float64))
