@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
     __shared__ unsigned top[kHamNq][kHamMaxKK];              // the kk smallest D^ so far, ascending
     __shared__ int cnt[kHamNq];
     __shared__ int cand[kHamNq][kHamCand];
+    __shared__ unsigned cval[kHamNq][kHamCand];              // D^ of every candidate (for the compaction below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long q0 = (long)blockIdx.x * kHamNq;
     for (int i = tid; i < kHamNq * kHamMaxKK; i += kHamWaves * 64) top[i / kHamMaxKK][i % kHamMaxKK] = 0xffffffffu;
@@ -235,14 +236,39 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
                     const unsigned vv = __shfl(v, bit, 64);
                     const unsigned lim2 = kth > 0xffffffffu - a.band ? 0xffffffffu : kth + a.band;
                     if (vv > lim2) continue;  // the bound has dropped since the ballot
+                    if (cnt[j] == kHamCand) {
+                        // The list is full of rows admitted against EARLIER, looser bounds (about kk (1 + ln(n_ref / kk)) rows
+                        // pass the running bound of a sweep in index order): keep what is still within band of the current
+                        // kk-th smallest value -- in place, order preserved, the whole wave at work.  Only a list that is
+                        // still full afterwards overflows.
+                        int kept = 0;
+#pragma unroll 1
+                        for (int c0 = 0; c0 < kHamCand; c0 += 64) {
+                            const int id = cand[j][c0 + lane];
+                            const unsigned cv = cval[j][c0 + lane];
+                            const bool keep = cv <= lim2;
+                            const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+                            const int dst = kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+                            __builtin_amdgcn_wave_barrier();  // (every lane has read its slot before any slot is rewritten: dst <= c0 + lane)
+                            if (keep) {
+                                cand[j][dst] = id;
+                                cval[j][dst] = cv;
+                            }
+                            kept += __builtin_popcountll(km);
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        if (lane == 0) cnt[j] = kept;
+                        __builtin_amdgcn_wave_barrier();
+                    }
                     if (lane == 0) {
                         const int c = cnt[j];
                         if (c >= 0) {
                             if (c < kHamCand) {
                                 cand[j][c] = j0 + 64 * u + bit;
+                                cval[j][c] = vv;
                                 cnt[j] = c + 1;
                             } else {
-                                cnt[j] = -1;  // overflow: the exact scan answers this query
+                                cnt[j] = -1;  // still full after the compaction: the exact scan answers this query
                             }
                         }
                         if (vv < top[j][KK - 1]) {  // keep the kk smallest, ascending
@@ -261,13 +287,28 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
         }
     }
     __syncthreads();
-    // candidates that are still within band of the FINAL kk-th smallest value (the early ones were admitted against looser bounds)
+    // out go the candidates that are still within band of the FINAL kk-th smallest value (the early ones were admitted against
+    // looser bounds): ascending order kept, the re-score reads fewer rows
     for (int j = wave; j < kHamNq; j += kHamWaves) {
         const long q = q0 + j;
         if (q >= a.nq) break;
         const int c = a.q_bad[q] ? -1 : cnt[j];
-        if (lane == 0) a.cand_cnt[q] = c;
-        for (int i = lane; i < c; i += 64) a.cand_id[q * kHamCand + i] = cand[j][i];
+        if (c < 0) {
+            if (lane == 0) a.cand_cnt[q] = -1;
+            continue;
+        }
+        const unsigned kth = top[j][KK - 1];
+        const unsigned lim = kth > 0xffffffffu - a.band ? 0xffffffffu : kth + a.band;
+        int kept = 0;
+        for (int c0 = 0; c0 < c; c0 += 64) {
+            const int i = c0 + lane;
+            const bool keep = i < c && cval[j][i < c ? i : 0] <= lim;
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+            const int dst = kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+            if (keep) a.cand_id[q * kHamCand + dst] = cand[j][i];
+            kept += __builtin_popcountll(km);
+        }
+        if (lane == 0) a.cand_cnt[q] = kept;
     }
 }
 #endif  // SKNNR_KERNELS_HAMMING

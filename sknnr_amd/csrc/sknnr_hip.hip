@@ -1012,8 +1012,12 @@ extern "C" int sknnr_index_set_hamming_weights(sknnr_index* ix, const double* w,
         for (int v : hb) any_bad = any_bad || v != 0;
         const int tpr = ham_row_dwords(n);
         bool rows_ok = n <= 4096 && hamming_rescore_lds(n) <= 150 * 1024;
+        if (rows_ok && ix->h_rrow.ensure((size_t)ix->n_ref * tpr) != hipSuccess) {
+            // (the row-major image takes a KiB per row and 512 trees: when it does not fit, the float64 scan serves the index)
+            (void)hipGetLastError();
+            rows_ok = false;
+        }
         if (rows_ok) {
-            HIP_TRY(ix->h_rrow.ensure((size_t)ix->n_ref * tpr));
             HIP_TRY(launch::hamming_rows(ix->ref64.p, ix->n_ref, n, tpr, ix->h_rrow.p, nullptr));
             HIP_TRY(hipDeviceSynchronize());
         }
@@ -1698,6 +1702,9 @@ int run_device(sknnr_index* ix, const void* xdev, long nq, const sknnr_query_opt
         HIP_TRY(launch::add_counter(ix->fail_count.p, ix->fail_total.p, st));
         ix->stats.coarse_queries += nq;
     } else {
+        // (weighted Hamming: the rows the integer pre-filter could not serve -- list overflow, ids beyond 16 bits -- count as
+        //  fallbacks too)
+        if (ham_int) HIP_TRY(launch::add_counter(ix->fail_count.p, ix->fail_total.p, st));
         ix->stats.exact_only_queries += nq;
     }
     HIP_TRY(hipEventRecord(ct.e1, st));

@@ -165,3 +165,26 @@ def test_narrow_tiles_through_the_estimators_equal_the_float64_call(dtype):
     dt, it = est.kneighbors(torch.as_tensor(q, device="cuda"))
     np.testing.assert_array_equal(it.cpu().numpy(), i0)
     np.testing.assert_array_equal(dt.cpu().numpy(), d0)
+
+
+def test_hamming_candidate_lists_are_compacted_before_they_overflow(N):
+    """candidates admitted early against the loose running bound used to fill the 192 slots of a query
+    for good (about kk (1 + ln(n_ref / kk)) admissions, plus ties: kk >= 16 at a million rows, sooner with uniform weights)
+    and the query fell to the full float64 scan.  The list is now compacted against the current bound when it is full and
+    against the final bound before it goes out: kk = 32 over 200,000 rows with uniform weights stays on the integer path,
+    bit-equal to the oracle."""
+    from oracle import oracle as O
+    from sknnr_amd import synth
+
+    ids_ref, ids_q = synth.make_forest_ids(200_000, 512, 60, seed=3)
+    w = np.random.default_rng(9).random(60) + 0.05
+    ix = N.Index(ids_ref)
+    ix.set_hamming_weights(w)
+    ix.reset_stats()
+    d, i = ix.kneighbors_host(ids_q, ix.make_opts(32, formula=N.FORMULA_HAMMING))
+    st = ix.stats()
+    assert st["exact_fallbacks"] <= 0.05 * len(ids_q), st
+    od, oi = O.kneighbors_hamming(ids_ref, ids_q[:64], w, 32)
+    np.testing.assert_array_equal(i[:64], oi)
+    np.testing.assert_array_equal(d[:64], od)
+    ix.close()
