@@ -63,6 +63,11 @@ def parse_args(argv=None):
     ap.add_argument("--gather-chunks", type=int, default=2, choices=[1, 2, 3, 4], help="N>1: calls a rank's share is split into (all but the last gather overlap compute)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (self-test of the N>1 path)")
+    ap.add_argument("--traffic", choices=["auto", "measure", "committed", "off"], default="auto",
+                    help="HBM bytes of the dominant kernel and of the step: 'measure' runs this bench twice more as a CHILD under "
+                         "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (counters only, no trace domains) before this process "
+                         "touches the GPU; 'auto' does so at N = 1 when rocprofv3 is on PATH, else quotes the committed passes")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-launch", action="store_true",
                     help="--gpus N > 1 outside a launcher: print the command that would start the N ranks and exit")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (default: a free one)")
@@ -257,6 +262,75 @@ def library_sha16():
         return None
 
 
+def measure_traffic(args, argv):
+    """HBM bytes per step, counted IN THIS RUN: the same command (headline only, three steps) as a child process under
+    `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` -- separate passes, counters only, as
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM, rocprofv3 PMC slots) prescribes: FETCH_SIZE takes 3 of the 4 TCC slots,
+    WRITE_SIZE 2; both print KiB; gfx950 counts a wide coalesced streaming read at half its bytes, so FETCH_SIZE is doubled
+    for the pre-filter (its reads are the LDS-DMA stage copies) and taken as read for the thread-per-row / gather kernels.
+    Called before this process imports torch (a profiler child must not be started from a process that holds the GPU)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None, "rocprofv3 is not on PATH"
+    keep = []
+    skip_next = False
+    for a in argv:  # the child: this run's shape arguments, headline only
+        if skip_next:
+            skip_next = False
+            continue
+        if a in ("--steps", "--warmup", "--traffic", "--gpus"):
+            skip_next = True
+            continue
+        if a.startswith(("--steps=", "--warmup=", "--traffic=", "--gpus=")) or a in ("--no-extras", "--no-cpu-baseline"):
+            continue
+        keep.append(a)
+    child = [sys.executable, os.path.abspath(__file__), *keep, "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+             "--traffic", "off", "--traffic-child"]
+    sums, launches = {}, {}
+    tmp = tempfile.mkdtemp(prefix="sknnr_traffic_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                proc = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", *child],
+                                      capture_output=True, text=True, timeout=420, env=env, cwd="/tmp")
+            except subprocess.TimeoutExpired:
+                return None, f"the {counter} pass did not finish in 420 s"
+            if proc.returncode != 0:
+                return None, f"the {counter} pass failed (rc {proc.returncode}): {proc.stderr[-300:]}"
+            rows = []
+            for f in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
+                rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "sknnr" in r["Kernel_Name"]]
+            if not rows:
+                return None, f"the {counter} pass wrote no counter rows"
+            grid_max = max(int(r["Grid_Size"]) for r in rows if "coarse" in r["Kernel_Name"])
+            for r in rows:
+                short = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                sums.setdefault(short, {}).setdefault(counter, 0.0)
+                sums[short][counter] += float(r["Counter_Value"])
+                if "coarse" in r["Kernel_Name"] and int(r["Grid_Size"]) == grid_max:
+                    launches.setdefault(counter, []).append(float(r["Counter_Value"]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    n_steps = len(launches["FETCH_SIZE"])  # bulk launches of the pre-filter = steps of the child (warm-up included)
+    if n_steps == 0 or len(launches["WRITE_SIZE"]) != n_steps:
+        return None, "the two passes saw different launch counts"
+    dominant = (2.0 * sum(launches["FETCH_SIZE"]) + sum(launches["WRITE_SIZE"])) * 1024.0 / n_steps
+    step = sum((2.0 if "coarse" in kn else 1.0) * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0) for kn, c in sums.items()) * 1024.0 / n_steps
+    by_kernel = {kn: ((2.0 if "coarse" in kn else 1.0) * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 / n_steps for kn, c in sums.items()}
+    return {"dominant_bytes_per_launch": dominant, "step_bytes": step, "steps_counted": n_steps,
+            "by_kernel_bytes_per_step": {k: v for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1])[:8]}}, (
+        "counted in this run: two child passes of this command under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; counters only), "
+        "FETCH_SIZE x2 for the pre-filter's wide LDS-DMA reads (gfx950 tallies them at half), KiB -> bytes, per bulk launch / per step")
+
+
 def committed_traffic(n_ref, d_t, k):
     """HBM bytes per query row from the committed rocprofv3 --pmc passes of this same command (counters cannot be
     collected inside the process): (dominant kernel, whole step, note), or (None, None, why)."""
@@ -389,6 +463,14 @@ def main():
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, argv))
+    # HBM traffic counted in-run (profiler children first: this process has not touched the GPU yet)
+    measured, measured_note = None, None
+    world_env = int(os.environ.get("WORLD_SIZE", 1))
+    if args.traffic in ("auto", "measure") and world_env == 1 and not args.force_dist and not args.traffic_child:
+        import shutil
+
+        if args.traffic == "measure" or shutil.which("rocprofv3"):
+            measured, measured_note = measure_traffic(args, argv)
     # Libraries print to stdout (RCCL's version banner at communicator creation, for one): the contract is ONE JSON line
     # there, so file descriptor 1 points at stderr until that line is written.
     sys.stdout.flush()
@@ -517,15 +599,25 @@ def main():
         rows_timed = st["coarse_rows_timed"] / args.steps
         achieved_tf, frac = mfma_frac(rows_timed, args.refs, d_t, coarse_ms)
         alg_bytes = nq * args.dims * 8 + args.refs * d_t * 8 + nq * k * 16
-        per_row, step_per_row, traffic_note = committed_traffic(args.refs, d_t, k)
-        traffic = per_row * rows_timed if per_row is not None else None
-        traffic_step = step_per_row * nq if step_per_row is not None else None
+        if measured is not None:
+            # per launch of the dominant kernel / per step, as counted (the child ran the same rows per step)
+            traffic, traffic_step, traffic_note, traffic_source = measured["dominant_bytes_per_launch"], measured["step_bytes"], measured_note, "measured"
+        elif args.traffic == "off":
+            traffic, traffic_step, traffic_note, traffic_source = None, None, "not requested (--traffic off)", None
+        else:
+            per_row, step_per_row, traffic_note = committed_traffic(args.refs, d_t, k)
+            traffic = per_row * rows_timed if per_row is not None else None
+            traffic_step = step_per_row * nq if step_per_row is not None else None
+            traffic_source = "committed" if traffic is not None else None
+            if measured_note:
+                traffic_note = f"in-run count unavailable ({measured_note}); " + traffic_note
         assert frac <= 1.0, (frac, coarse_ms, st)
         roofline = {
             "kernel": "sknnr::coarse2_kernel<KS=%d,M=%d,WAVES=16> (f16 split MFMA pre-filter: seeded thresholds, main hi.hi products swept on the matrix "
                       "pipe with the skip test in their shadow, hits corrected (lo.hi + hi.lo) in the batched flush; lane-local top-M)" % ((d_t + 15) // 16, 6 if k <= 5 else 8),
             "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": frac, "traffic": traffic, "traffic_note": traffic_note,
+            "frac": frac, "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note,
+            "traffic_by_kernel_bytes_per_step": measured["by_kernel_bytes_per_step"] if measured else None,
             "traffic_all_kernels_of_the_step": traffic_step,
             "traffic_over_algorithmic_bytes_step": (traffic_step / alg_bytes) if traffic_step else None,
             "algorithmic_bytes_step": alg_bytes,

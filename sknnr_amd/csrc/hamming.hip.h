@@ -143,17 +143,29 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
     __shared__ int cnt[kHamNq];
     __shared__ int cand[kHamNq][kHamCand];
     __shared__ unsigned cval[kHamNq][kHamCand];              // D^ of every candidate (for the compaction below)
+    __shared__ unsigned seed_kth[kHamNq];                     // upper bound of the final kk-th smallest D^ (seeding pass)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long q0 = (long)blockIdx.x * kHamNq;
     for (int i = tid; i < kHamNq * kHamMaxKK; i += kHamWaves * 64) top[i / kHamMaxKK][i % kHamMaxKK] = 0xffffffffu;
-    if (tid < kHamNq) cnt[tid] = 0;
+    if (tid < kHamNq) {
+        cnt[tid] = 0;
+        seed_kth[tid] = 0xffffffffu;
+    }
     __syncthreads();
     const int KK = a.kk;
+    // Seeding (many neighbours): rows that share no leaf with a query all sit at the SAME largest distance, and while fewer
+    // than kk closer rows have been seen every one of them is within the running bound -- the candidate list of a query
+    // filled up in the first few hundred rows whatever its length (kk = 16: a fifth of the queries, kk = 32: nearly all fell
+    // to the float64 scan).  A first pass over a prefix of the rows only ranks (no candidates): its kk-th smallest value
+    // bounds the final one from above, and the real sweep starts with it.
+    const int seed_rows = KK >= 8 ? min(a.n_ref, max(256, min(4096, a.n_ref / 16)) / 256 * 256) : 0;
     const uint32_t* qbase = a.qimg + q0;  // + p * nq_pad: 16 consecutive dwords, workgroup-uniform
     uint32_t ones = 0x00010001u;
     asm volatile("" : "+v"(ones));  // (a vector register, loaded once)
 
-    for (int j0 = 0; j0 < a.n_ref; j0 += kHamWaves * 64) {
+    for (int phase = seed_rows > 0 ? 0 : 1; phase < 2; ++phase) {
+    const int j_end = phase == 0 ? seed_rows : a.n_ref;
+    for (int j0 = 0; j0 < j_end; j0 += kHamWaves * 64) {
         const int r = j0 + tid;
         const uint32_t* rcol = a.rimg + (r < a.n_ref_pad ? r : 0);
         unsigned acc[kHamNq];
@@ -224,7 +236,7 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
         for (int jj = 0; jj < kHamNq / kHamWaves; ++jj) {
             const int j = wave * (kHamNq / kHamWaves) + jj;
             if (q0 + j >= a.nq) break;
-            unsigned kth = top[j][KK - 1];
+            unsigned kth = min(top[j][KK - 1], seed_kth[j]);
 #pragma unroll 1
             for (int u = 0; u < kHamWaves; ++u) {
                 const unsigned v = dbuf[j][64 * u + lane];
@@ -236,6 +248,19 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
                     const unsigned vv = __shfl(v, bit, 64);
                     const unsigned lim2 = kth > 0xffffffffu - a.band ? 0xffffffffu : kth + a.band;
                     if (vv > lim2) continue;  // the bound has dropped since the ballot
+                    if (phase == 0) {  // seeding pass: rank only
+                        if (lane == 0 && vv < top[j][KK - 1]) {
+                            int pos = KK - 1;
+                            while (pos > 0 && top[j][pos - 1] > vv) {
+                                top[j][pos] = top[j][pos - 1];
+                                --pos;
+                            }
+                            top[j][pos] = vv;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        kth = top[j][KK - 1];
+                        continue;
+                    }
                     if (cnt[j] == kHamCand) {
                         // The list is full of rows admitted against EARLIER, looser bounds (about kk (1 + ln(n_ref / kk)) rows
                         // pass the running bound of a sweep in index order): keep what is still within band of the current
@@ -281,11 +306,19 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    kth = top[j][KK - 1];
+                    kth = min(top[j][KK - 1], seed_kth[j]);
                 }
             }
         }
     }
+    if (phase == 0) {  // the seed's kk-th smallest value becomes the starting bound; the ranking starts over (same rows again)
+        __syncthreads();
+        if (tid < kHamNq) seed_kth[tid] = top[tid][KK - 1];
+        __syncthreads();
+        for (int i = tid; i < kHamNq * kHamMaxKK; i += kHamWaves * 64) top[i / kHamMaxKK][i % kHamMaxKK] = 0xffffffffu;
+        __syncthreads();
+    }
+    }  // phases
     __syncthreads();
     // out go the candidates that are still within band of the FINAL kk-th smallest value (the early ones were admitted against
     // looser bounds): ascending order kept, the re-score reads fewer rows
@@ -297,7 +330,7 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
             if (lane == 0) a.cand_cnt[q] = -1;
             continue;
         }
-        const unsigned kth = top[j][KK - 1];
+        const unsigned kth = top[j][KK - 1];  // (the full ranking: at most the seed's bound)
         const unsigned lim = kth > 0xffffffffu - a.band ? 0xffffffffu : kth + a.band;
         int kept = 0;
         for (int c0 = 0; c0 < c; c0 += 64) {

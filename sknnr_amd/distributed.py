@@ -402,6 +402,12 @@ class RefShardedKNN:
             k = int(n_neighbors)
         kk = k + (1 if X is None else 0)
         a, b = self.bounds
+        # The same test with the same outcome on EVERY rank, before any collective: shard sizes differ by at most one row, so
+        # the smallest shard decides -- a rank that raised alone would leave the others blocked in the all-gather.
+        smallest = self.n_ref // self.world_size
+        if smallest < kk:
+            raise ValueError(f"the smallest of the {self.world_size} reference shards holds {smallest} rows, fewer than the {kk} "
+                             "neighbours asked for of every shard")
         val, idx = self._local_candidates(X, kk, a, b)
         as_numpy = isinstance(idx, np.ndarray)
         tv = val if isinstance(val, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(val))

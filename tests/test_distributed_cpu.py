@@ -139,6 +139,13 @@ def _ref_worker(rank, world, port, out_dir):
                 ds, is_ = sh.kneighbors(None, 4, use_deterministic_ordering=det)
                 tag = f"{formula}_{int(det)}"
                 res.update({f"d_{tag}": d, f"i_{tag}": i, f"ds_{tag}": ds, f"is_{tag}": is_, f"replays_{tag}": np.asarray(replays)})
+        # more neighbours than the smallest shard holds: EVERY rank refuses before the collective (a rank that
+        # raised alone would leave the others blocked in the all-gather)
+        try:
+            sh.kneighbors(x_q, len(x_ref) // world + 1)
+            res["refused"] = np.asarray(False)
+        except ValueError as err:
+            res["refused"] = np.asarray("smallest" in str(err))
         np.savez(os.path.join(out_dir, f"ref_rank{rank}.npz"), **res)
     finally:
         dist.destroy_process_group()
@@ -172,6 +179,7 @@ def test_reference_sharded_search_matches_the_unsharded_call(tmp_path, world):
             tag = f"{formula}_{int(det)}"
             for rank in range(world):
                 r = np.load(os.path.join(str(tmp_path), f"ref_rank{rank}.npz"))
+                assert bool(r["refused"])
                 np.testing.assert_array_equal(r[f"i_{tag}"], i)
                 np.testing.assert_array_equal(r[f"d_{tag}"], d)
                 np.testing.assert_array_equal(r[f"is_{tag}"], is_)
