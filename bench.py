@@ -334,17 +334,17 @@ def measure_traffic(args, argv):
 def committed_traffic(n_ref, d_t, k):
     """HBM bytes per query row from the committed rocprofv3 --pmc passes of this same command (counters cannot be
     collected inside the process): (dominant kernel, whole step, note), or (None, None, why)."""
-    path = os.path.join(ROOT, "profiles", "r03_coarse_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r04_coarse_pmc.json")
     if (n_ref, d_t, k) != (50_000, 32, 5):
         return None, None, "no committed counter passes for this shape"
     if not os.path.exists(path):
-        return None, None, "profiles/r03_coarse_pmc.json is missing"
+        return None, None, "profiles/r04_coarse_pmc.json is missing"
     pmc = json.load(open(path))
     if pmc.get("lib_sha16") != library_sha16():
-        return None, None, (f"profiles/r03_coarse_pmc.json was measured on library {pmc.get('lib_sha16')}, this run loads "
+        return None, None, (f"profiles/r04_coarse_pmc.json was measured on library {pmc.get('lib_sha16')}, this run loads "
                             f"{library_sha16()}: not quoted")
     return pmc["hbm_bytes_per_query_row"], pmc.get("step_hbm_bytes_per_query_row"), (
-        "profiles/r03_coarse_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 only for the kernels whose reads are "
+        "profiles/r04_coarse_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 only for the kernels whose reads are "
         "wide coalesced: the pre-filter's LDS-DMA stages; WRITE_SIZE as read), same library build, scaled to this step's rows")
 
 

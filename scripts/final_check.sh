@@ -3,11 +3,11 @@
 # benchmark-sized cases.  usage: bash scripts/final_check.sh [fuzz seconds]
 secs=${1:-300}
 mkdir -p gpurun_out/final
-python bench.py > gpurun_out/r03_bench_output.json 2> gpurun_out/r03_bench_err.txt || exit 1
-python scripts/bench_fields.py gpurun_out/r03_bench_output.json
+python bench.py > gpurun_out/r04_bench_output.json 2> gpurun_out/r04_bench_err.txt || exit 1
+python scripts/bench_fields.py gpurun_out/r04_bench_output.json
 python - <<'PY'
 import json
-r = json.load(open("gpurun_out/r03_bench_output.json"))
+r = json.load(open("gpurun_out/r04_bench_output.json"))
 print("frac", r["roofline"]["frac"], "traffic", r["roofline"]["traffic"], "step traffic / algorithmic", r["roofline"]["traffic_over_algorithmic_bytes_step"],
       "host calls ms", r.get("host_to_host_calls_ms"), "lib", r["library_sha16"])
 PY
