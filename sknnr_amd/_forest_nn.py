@@ -24,7 +24,15 @@ __all__ = ["WeightedTreesNNRegressor", "RFNNRegressor", "GBNNRegressor"]
 
 class WeightedTreesNNRegressor(YFitMixin, TransformedKNeighborsRegressor):
     """Base of the tree-node regressors: brute-force search under the Hamming metric with one weight per
-    tree = the transformer's tree weight x the forest's weight / trees per boosting iteration."""
+    tree = the transformer's tree weight x the forest's weight / trees per boosting iteration.
+
+    Exactly tied rows: distances are bit-identical to the reference's (scipy's ``cdist(..., "hamming", w=w)``).  Among
+    reference rows tied EXACTLY at the k-th distance the device keeps the lowest index first; the reference keeps what
+    ``np.argpartition`` keeps (REF src/sknnr/_weighted_trees.py:53-59 -> SKL/neighbors/_base.py:733-760).  For the
+    reference's own choice -- its committed RFNN / GBNN regression files are then matched row for row -- fit and query
+    under ``sknnr_amd.hamming_tie_policy("numpy")`` (or ``set_hamming_tie_policy`` / ``SKNNR_HAMMING_TIES=numpy``): the
+    tied rows' full distance rows come back from the device and the selection is replayed with the host's numpy
+    (INTEGRATION.md, "Hamming ties")."""
 
     def __init__(self, *, n_neighbors=5, weights="uniform", n_jobs=None):
         super().__init__(n_neighbors=n_neighbors, weights=weights, algorithm="brute", metric="hamming",
