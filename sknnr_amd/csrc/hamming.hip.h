@@ -100,6 +100,10 @@ __device__ __forceinline__ void ham_sload(u32x16& q, uint32_t& w, const uint32_t
     asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0" : "=&s"(q), "=&s"(w) : "s"(qp), "s"(wp) : "memory");
 }
 
+// many neighbours: the candidate lists are seeded and compacted (hamming_coarse_kernel), which takes 12 KB more LDS
+__host__ __device__ constexpr bool ham_compacts(int kk) { return kk >= 8; }
+__host__ __device__ constexpr size_t hamming_coarse_lds(int kk) { return ham_compacts(kk) ? (size_t)16 * 192 * sizeof(unsigned) : 0; }
+
 struct HammingArgs {
     const uint32_t* rimg;   // [tp][n_ref_pad] two 16-bit ids per dword
     const uint32_t* wq;     // [tp] two 16-bit weights per dword
@@ -142,7 +146,10 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
     __shared__ unsigned top[kHamNq][kHamMaxKK];              // the kk smallest D^ so far, ascending
     __shared__ int cnt[kHamNq];
     __shared__ int cand[kHamNq][kHamCand];
-    __shared__ unsigned cval[kHamNq][kHamCand];              // D^ of every candidate (for the compaction below)
+    // D^ of every candidate, for the compaction below: dynamic LDS, present only when many neighbours are searched
+    // (ham_compacts(kk)) -- a call for a few neighbours never fills its lists and keeps five workgroups per CU (30 KB each)
+    extern __shared__ unsigned cval_dyn[];
+    unsigned (*cval)[kHamCand] = (unsigned (*)[kHamCand])cval_dyn;
     __shared__ unsigned seed_kth[kHamNq];                     // upper bound of the final kk-th smallest D^ (seeding pass)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long q0 = (long)blockIdx.x * kHamNq;
@@ -153,12 +160,13 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
     }
     __syncthreads();
     const int KK = a.kk;
+    const bool compacts = ham_compacts(KK);
     // Seeding (many neighbours): rows that share no leaf with a query all sit at the SAME largest distance, and while fewer
     // than kk closer rows have been seen every one of them is within the running bound -- the candidate list of a query
     // filled up in the first few hundred rows whatever its length (kk = 16: a fifth of the queries, kk = 32: nearly all fell
     // to the float64 scan).  A first pass over a prefix of the rows only ranks (no candidates): its kk-th smallest value
     // bounds the final one from above, and the real sweep starts with it.
-    const int seed_rows = KK >= 8 ? min(a.n_ref, max(256, min(4096, a.n_ref / 16)) / 256 * 256) : 0;
+    const int seed_rows = compacts ? min(a.n_ref, max(256, min(4096, a.n_ref / 16)) / 256 * 256) : 0;
     const uint32_t* qbase = a.qimg + q0;  // + p * nq_pad: 16 consecutive dwords, workgroup-uniform
     uint32_t ones = 0x00010001u;
     asm volatile("" : "+v"(ones));  // (a vector register, loaded once)
@@ -261,7 +269,7 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
                         kth = top[j][KK - 1];
                         continue;
                     }
-                    if (cnt[j] == kHamCand) {
+                    if (compacts && cnt[j] == kHamCand) {
                         // The list is full of rows admitted against EARLIER, looser bounds (about kk (1 + ln(n_ref / kk)) rows
                         // pass the running bound of a sweep in index order): keep what is still within band of the current
                         // kk-th smallest value -- in place, order preserved, the whole wave at work.  Only a list that is
@@ -290,7 +298,7 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
                         if (c >= 0) {
                             if (c < kHamCand) {
                                 cand[j][c] = j0 + 64 * u + bit;
-                                cval[j][c] = vv;
+                                if (compacts) cval[j][c] = vv;
                                 cnt[j] = c + 1;
                             } else {
                                 cnt[j] = -1;  // still full after the compaction: the exact scan answers this query
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
         int kept = 0;
         for (int c0 = 0; c0 < c; c0 += 64) {
             const int i = c0 + lane;
-            const bool keep = i < c && cval[j][i < c ? i : 0] <= lim;
+            const bool keep = i < c && (!compacts || cval[j][i < c ? i : 0] <= lim);
             const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
             const int dst = kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
             if (keep) a.cand_id[q * kHamCand + dst] = cand[j][i];

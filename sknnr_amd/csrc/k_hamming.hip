@@ -17,7 +17,8 @@ hipError_t hamming_rows(const double* x, long n, int t, int tpr, uint32_t* rows,
 }
 
 hipError_t hamming_coarse(const HammingArgs& a, hipStream_t st) {
-    hamming_coarse_kernel<<<dim3((unsigned)((a.nq + kHamNq - 1) / kHamNq)), dim3(kHamWaves * 64), 0, st>>>(a);
+    static_assert(hamming_coarse_lds(8) == (size_t)kHamNq * kHamCand * sizeof(unsigned), "one D^ per candidate slot");
+    hamming_coarse_kernel<<<dim3((unsigned)((a.nq + kHamNq - 1) / kHamNq)), dim3(kHamWaves * 64), hamming_coarse_lds(a.kk), st>>>(a);
     return hipGetLastError();
 }
 
