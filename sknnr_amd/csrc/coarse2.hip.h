@@ -31,9 +31,8 @@
 //     launch_coarse2_ks).
 // Round 3 (DESIGN.md sections 4.1, 4.2; profiles/r03_*):
 //   * the image is in CELL order and the rows of a call are bucketed by cell (bucket.hip.h): a workgroup works on positions,
-//     starts its sweep (and takes its seeds) at the stage its middle row's cell names, and reads the queries' lo fragments
-//     from a position-ordered copy it makes at its start (qlo);
-//   * the flush walks the entries of a query's two lanes as ONE sequence, two per trip (SKNNR_V2_PAIR_FLUSH);
+//     starts its sweep (and takes its seeds) at the stage its middle row's cell names;
+//   * (round 3: the flush walked the entries of a query's two lanes as one sequence, two per trip; round 4: wave flush)
 //   * thresholds of a rank beyond one list over the two lists of a query kept as one pool (template parameter E):
 //     6 .. 31 neighbours on lists of 6 / 8 / 16.
 #pragma once
@@ -41,9 +40,8 @@
 
 // Timing experiments that produce WRONG results (sweeps without visits, corrections or stage barriers) compile only in
 // development builds that say so; the product build (sknnr_amd/_build.py) never defines any of them.
-#if !defined(SKNNR_EXPERIMENTS) && (defined(SKNNR_V2_SWEEP_ONLY) || defined(SKNNR_V2_NO_CORR) || defined(SKNNR_V2_NO_BARRIER) || \
-                                    defined(SKNNR_V2_NO_SEED))
-#error "SKNNR_V2_SWEEP_ONLY / NO_CORR / NO_BARRIER / NO_SEED are timing experiments with wrong results: add -DSKNNR_EXPERIMENTS"
+#if !defined(SKNNR_EXPERIMENTS) && (defined(SKNNR_V2_SWEEP_ONLY) || defined(SKNNR_V2_NO_BARRIER) || defined(SKNNR_V2_NO_SEED))
+#error "SKNNR_V2_SWEEP_ONLY / NO_BARRIER / NO_SEED are timing experiments with wrong results: add -DSKNNR_EXPERIMENTS"
 #endif
 
 namespace sknnr {
@@ -74,12 +72,6 @@ __host__ __device__ constexpr int seed_tiles_for(long n_tiles, int tps) {
     const long stages = want / tps < 1 ? 1 : want / tps;
     return (int)(stages * tps);
 }
-#ifndef SKNNR_V2_PAIR_FLUSH
-#define SKNNR_V2_PAIR_FLUSH 1  // the flush walks the entries of the two lanes of a query as one sequence, two per trip
-#endif
-#ifndef SKNNR_V2_WAVE_FLUSH
-#define SKNNR_V2_WAVE_FLUSH 1  // round 4: the queued entries of the whole wave are compacted and corrected 32 per trip
-#endif
 constexpr int kCoarse2Waves = SKNNR_V2_WAVES;
 constexpr int kCoarse2Nqb = 2;
 constexpr int kQueueCap = 5;      // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
@@ -240,8 +232,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
                // Query bucketing (bucket.hip.h): the kernel works on POSITIONS pos0 .. of the chunk; position p holds row
                // qperm[p] (null: the row itself).  A workgroup starts its sweep at the stage its middle row's cell names.
                int pos0, const int* __restrict__ qperm, const unsigned char* __restrict__ qcell,
-               const int* __restrict__ cell_stage,
-               uint4* __restrict__ qlo) {       // scratch: [n_qblocks][KS][64] lo fragments, fragment order by position
+               const int* __restrict__ cell_stage) {
     constexpr int TPS = tiles_per_stage2(KS);
     constexpr int TB = tile2_bytes(KS);
     constexpr int STAGE = TPS * TB;
@@ -290,21 +281,8 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         // The flush needs the lo fragments of this lane's column again and again: they are copied once into
         // fragment order by position (this wave's own 1-KiB blocks, written and later read by the same lanes), so that
         // every later fetch is one coalesced 1-KiB load instead of 64 pieces out of 32 rows' lines.
-        if constexpr (!SKNNR_V2_WAVE_FLUSH) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                qlo[((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane] = __builtin_bit_cast(uint4, qfrag(r, 1, s));
-        }
     }
 
-#ifdef SKNNR_V2_BL_RESIDENT  // experiment: the queries' lo fragments stay in registers (12-wave geometry: 168 VGPRs)
-    half8 blr[NQB][KS];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb)
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            blr[qb][s] = qfrag(qrow_of(qb), 1, s);
-#endif
     float vals[NQB][M];
     int idxs[NQB][M];
 #ifdef SKNNR_COARSE_COUNTERS
@@ -464,165 +442,6 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         TSTAMP(2);
     };
 
-    // ---- flush: correct every queued entry, insert, tighten the pair's threshold ---------------------------
-    auto flush = [&](int qb) {
-        TSTAMP(1);  // (visit scan up to here)
-        const unsigned qlane = qwave + qb * (kQueueCap * 512);
-        const int frag_off = (32 * half) * 16;  // this lane's K half inside a fragment row group
-        half8 bl[KS];  // this lane's lo fragments of the queries (not kept during the sweep)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-#ifdef SKNNR_V2_BL_RESIDENT
-            bl[s] = blr[qb][s];
-#else
-            bl[s] = __builtin_bit_cast(half8, qlo[((size_t)(pos0 / 32 + qb0 + qb) * KS + s) * 64 + lane]);
-#endif
-        }
-        CTR(6, 1);
-#if SKNNR_V2_PAIR_FLUSH && !defined(SKNNR_V2_NO_CORR) && !defined(SKNNR_V2_FLUSH_COMBINED)
-        constexpr bool PAIR_FLUSH = true;
-#else
-        constexpr bool PAIR_FLUSH = false;
-#endif
-        if constexpr (PAIR_FLUSH) {
-            // The entries of the two lanes of a query (lower lane's first, then the upper lane's) are ONE sequence, taken
-            // two per trip: entry 2i is finished by the lower lane and goes to ITS list, entry 2i + 1 by the upper lane.
-            // A flush is triggered by one lane holding kQueueFlushAt entries while most hold none or one: the trips are
-            // ceil(most entries of a PAIR / 2) instead of the most entries of a LANE -- two instead of three as a rule.
-            // Which of the two lists holds an entry does not matter to the certificate (what a list of M drops is >= its
-            // last entry >= the M-th smallest of the union, whatever rows it was fed), and the corrected value is the
-            // same sum of the same two halves.
-            const int c_par = __shfl_xor(cnt[qb], 32, 64);
-            const int c_low = half ? c_par : cnt[qb];
-            const int total = cnt[qb] + c_par;
-            const unsigned q_low = half ? qlane - 256u : qlane;  // the lower lane's slots; the upper lane's are 256 bytes on
-            auto slot_of = [&](int n) { return n < c_low ? q_low + (unsigned)n * 512u : q_low + 256u + (unsigned)(n - c_low) * 512u; };
-            for (int i = 0; __builtin_amdgcn_ballot_w64(2 * i < total) != 0; ++i) {
-                CTR(7, 1);
-                CTR(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(2 * i + half < total)));
-                const bool on0 = 2 * i < total, on1 = 2 * i + 1 < total;
-                unsigned long long e0, e1;
-                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(e0), "=&v"(e1)
-                             : "v"(slot_of(on0 ? 2 * i : 0)), "v"(slot_of(on1 ? 2 * i + 1 : 0))
-                             : "memory");
-                const int pos_0 = on0 ? (int)(e0 >> 32) : 0, pos_1 = on1 ? (int)(e1 >> 32) : 0;
-                auto partial = [&](int pos) {  // this lane's K half of the two correction products of one entry
-                    const unsigned row = (unsigned)(pos & 31) * 16u + (unsigned)frag_off;
-                    const unsigned oh = (unsigned)(pos >> 5) * (unsigned)TB + row;
-                    const unsigned ol = (unsigned)(pos >> 5) * (unsigned)(KS * 1024) + row;
-                    float acc = 0.f;
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        const half8 fl = *(const half8*)(rlo + ol + s * 1024);
-                        const half8 fh = *(const half8*)(rhi + oh + s * 1024);
-                        acc = dot8(fl, bh[qb][s], acc);
-                        acc = dot8(fh, bl[s], acc);
-                    }
-                    return acc;
-                };
-                const float part_0 = partial(pos_0);
-                __builtin_amdgcn_sched_barrier(0);
-                const float part_1 = partial(pos_1);
-                const float other = __shfl_xor(half ? part_0 : part_1, 32, 64);  // the partner's half of the entry I finish
-                const unsigned long long e_mine = half ? e1 : e0;
-                const float cv = __uint_as_float((unsigned)e_mine) + ((half ? part_1 : part_0) + other);
-                const bool on = half ? on1 : on0;
-                if constexpr (E == 0) {
-                    if (on && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, (int)(e_mine >> 32));
-                } else {
-                    // pooled lists (pair_union_rank): what this list lets go of is handed to the partner's at once, unless
-                    // it is no smaller than `loose` (which stays above the query's final threshold) -- rare once both lists
-                    // are full, and then one ballot
-                    float out_v = FLT_MAX;
-                    int out_i = -1;
-                    if (on) {
-                        if (cv < vals[qb][M - 1]) {
-                            out_v = vals[qb][M - 1];
-                            out_i = idxs[qb][M - 1];
-                            list_insert<M>(vals[qb], idxs[qb], cv, (int)(e_mine >> 32));
-                        } else {
-                            out_v = cv;
-                            out_i = (int)(e_mine >> 32);
-                        }
-                    }
-                    const bool offer = out_v < loose[qb];
-                    if (__builtin_amdgcn_ballot_w64(offer) != 0) {
-                        const float in_v = __shfl_xor(offer ? out_v : FLT_MAX, 32, 64);
-                        const int in_i = __shfl_xor(out_i, 32, 64);
-                        if (in_v < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], in_v, in_i);
-                    }
-                }
-            }
-        } else
-        for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt[qb]) != 0; ++i) {
-            CTR(7, 1);
-            CTR(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < cnt[qb])));
-            const bool active = i < cnt[qb];
-            unsigned long long e = 0;
-            if (active) e = queue_load(qlane + i * 512);
-            const float ev = __uint_as_float((unsigned)e);
-            const int pos_own = active ? (int)(e >> 32) : 0;
-            const int pos_par = __shfl_xor(pos_own, 32, 64);
-            // partial correction sums over this lane's K half, for its own entry and then for the partner's
-            // (one after the other: eight fragment registers at a time; 32-bit offsets from the uniform bases)
-            auto partial = [&](int pos) {
-                const unsigned row = (unsigned)(pos & 31) * 16u + (unsigned)frag_off;
-                const unsigned oh = (unsigned)(pos >> 5) * (unsigned)TB + row;
-                const unsigned ol = (unsigned)(pos >> 5) * (unsigned)(KS * 1024) + row;
-                float acc = 0.f;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const half8 fl = *(const half8*)(rlo + ol + s * 1024);
-                    const half8 fh = *(const half8*)(rhi + oh + s * 1024);
-                    acc = dot8(fl, bh[qb][s], acc);
-                    acc = dot8(fh, bl[s], acc);
-                }
-                return acc;
-            };
-#ifdef SKNNR_V2_NO_CORR  // timing experiment: entries inserted with their main values
-            const float part_own = 0.f, part_par = (float)pos_par * 0.f;
-#elif defined(SKNNR_V2_FLUSH_COMBINED)  // experiment: the gathers of both entries go out together (one round trip per iteration)
-            half8 fo[2 * KS], fp[2 * KS];
-            auto gather = [&](int pos, half8 (&f)[2 * KS]) {
-                const unsigned row = (unsigned)(pos & 31) * 16u + (unsigned)frag_off;
-                const unsigned oh = (unsigned)(pos >> 5) * (unsigned)TB + row;
-                const unsigned ol = (unsigned)(pos >> 5) * (unsigned)(KS * 1024) + row;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    f[2 * s] = *(const half8*)(rlo + ol + s * 1024);
-                    f[2 * s + 1] = *(const half8*)(rhi + oh + s * 1024);
-                }
-            };
-            auto reduce = [&](const half8 (&f)[2 * KS]) {
-                float acc = 0.f;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    acc = dot8(f[2 * s], bh[qb][s], acc);
-                    acc = dot8(f[2 * s + 1], bl[s], acc);
-                }
-                return acc;
-            };
-            gather(pos_own, fo);
-            gather(pos_par, fp);
-            const float part_own = reduce(fo);
-            const float part_par = reduce(fp);
-#else
-            const float part_own = partial(pos_own);
-            __builtin_amdgcn_sched_barrier(0);
-            const float part_par = partial(pos_par);
-#endif
-            const float from_partner = __shfl_xor(part_par, 32, 64);  // the partner's half of MY entry
-            const float cv = ev + (part_own + from_partner);
-            static_assert(E == 0 || PAIR_FLUSH, "pooled lists hand entries over inside the pair flush");
-            if (active && cv < vals[qb][M - 1]) list_insert<M>(vals[qb], idxs[qb], cv, pos_own);
-        }
-        cnt[qb] = 0;
-        const float tight = pair_union_rank<M, E>(vals[qb]) + margin[qb];
-        loose[qb] = loose[qb] != loose[qb] ? loose[qb] : min2f(loose[qb], tight);  // (NaN = poisoned: stays)
-        TSTAMP(2);  // flush
-    };
-
     // ---- one unit: skip test on the main products, visit = queue every value below threshold + margin ------
     // The visit looks at the registers of the groups that can hold a hit and appends.  The queue is flushed at the END of a
     // visit once a lane holds kQueueFlushAt entries, when the accumulator is dead and its registers are free
@@ -662,12 +481,8 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
             }
         }
         if (want > kQueueCap) loose[qb] = __builtin_nanf("");
-        if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) {
-            if constexpr (SKNNR_V2_WAVE_FLUSH) flush_wave(qb);
-            else flush(qb);
-        } else {
-            TSTAMP(1);  // visit scan without a flush
-        }
+        if (__builtin_amdgcn_ballot_w64(cnt[qb] >= kQueueFlushAt) != 0) flush_wave(qb);
+        else TSTAMP(1);  // visit scan without a flush
     };
 
     // ---- seeding: a valid starting threshold from the first kSeedTiles tiles ------------------------------
@@ -755,8 +570,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
     TSTAMP(0);
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-        if constexpr (SKNNR_V2_WAVE_FLUSH) flush_wave(qb);
-        else flush(qb);
+        flush_wave(qb);
         const size_t q = (size_t)qrow_of(qb);
         const size_t base = (q * 2 + half) * M;
         // a poisoned query (dropped hits) must fail the certificate: a NaN bound never certifies

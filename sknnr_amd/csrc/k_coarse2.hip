@@ -25,7 +25,7 @@ hipError_t go(const launch::Coarse2Launch& L, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return e;
     kern<<<dim3((unsigned)(L.rows / QPB)), dim3(WAVES * 64), sh, st>>>(L.rhi, L.rlo, L.n_stages, L.qimg, L.qnc, L.skip_scale, L.n_sentinel,
-                                                                   L.cand_val, L.cand_idx, L.pos0, L.qperm, L.qcell, L.cell_stage, L.qlo);
+                                                                   L.cand_val, L.cand_idx, L.pos0, L.qperm, L.qcell, L.cell_stage);
     return hipGetLastError();
 }
 

@@ -67,7 +67,6 @@ struct Coarse2Launch {
     const int* qperm;
     const unsigned char* qcell;
     const int* cell_stage;
-    uint4* qlo;
     long rows;  // positions [pos0, pos0 + rows) of the chunk (a multiple of the workgroup's rows)
 };
 constexpr int kNoInstance = -1;  // the (ks, list length, waves, rank) combination has no compiled kernel

@@ -256,7 +256,6 @@ struct sknnr_index {
     DevBuf<int> cell_stage;        // [2^depth] stage at which a workgroup of that cell starts its sweep
     DevBuf<unsigned char> qcell;   // workspace: cell of every query row of the chunk
     DevBuf<int> qperm, cell_hist;  // workspace: position -> row; [2][kCellMax] rows per cell / cursors
-    DevBuf<uint4> qlo;             // workspace: the queries' lo fragments in position order (written by the pre-filter itself)
 
     // workspace (one chunk)
     DevBuf<double> xt, qnc, xstage, dist_stage, pred_stage;
@@ -319,7 +318,7 @@ struct sknnr_index {
         perm.release();
         perm2.release();
         cell_axes.release(); cell_centre.release(); cell_thr.release(); cell_stage.release();
-        qcell.release(); qperm.release(); cell_hist.release(); qlo.release();
+        qcell.release(); qperm.release(); cell_hist.release();
         h_rimg.release(); h_wq.release(); h_qimg.release(); h_rrow.release(); h_bad.release(); h_cand_cnt.release(); h_cand_id.release();
         qimg.release();
         cand_val.release();
@@ -1244,7 +1243,7 @@ int launch_coarse2_waves(sknnr_index* ix, int m_list, int waves, long row0, long
     launch::Coarse2Launch L{ix->rhi2.p, ix->rlo2.p, ix->n_stages2, ix->qimg.p, ix->qnc.p, (float)(std::ldexp(1.0, -9) * ix->ymax * 1.02),
                             extra != 0 ? 0 : m_list - (kk + 1), ix->cand_val.p, ix->cand_idx.p, (int)row0,
                             bucketed ? ix->qperm.p : nullptr, bucketed ? ix->qcell.p : nullptr,
-                            bucketed ? ix->cell_stage.p : nullptr, ix->qlo.p, rows};
+                            bucketed ? ix->cell_stage.p : nullptr, rows};
     hipError_t e = hipSuccess;
     if (launch::coarse2(ix->ks, m_list, waves, extra, L, st, &e) == launch::kNoInstance)
         return fail(SKNNR_ERR_UNSUPPORTED, "no second-generation coarse kernel for ks = %d, list length %d, %d waves, rank + %d", ix->ks,
@@ -1473,7 +1472,6 @@ int run_device(sknnr_index* ix, const void* xdev, long nq, const sknnr_query_opt
         HIP_TRY(ix->qcell.ensure((size_t)cap_pad));
         HIP_TRY(ix->qperm.ensure((size_t)cap_pad));
     }
-    if (coarse && ix->ks <= 4) HIP_TRY(ix->qlo.ensure((size_t)(cap_pad / 32) * ix->ks * 64));
     if (coarse) {
         HIP_TRY(ix->cand_val.ensure((size_t)cap_pad * 2 * coarse_list_len(ix, kk)));
         HIP_TRY(ix->cand_idx.ensure((size_t)cap_pad * 2 * coarse_list_len(ix, kk)));
