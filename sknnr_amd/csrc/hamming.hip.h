@@ -195,7 +195,9 @@ __global__ void __launch_bounds__(kHamWaves * 64) hamming_coarse_kernel(HammingA
             for (int u = 0; u < 4; ++u) {
                 // (scalar loads return out of order: the only wait is for all of them -- so the next pair's load goes out
                 //  once this pair's has landed, and travels during this pair's arithmetic)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (the loaded registers are operands of the wait: what consumes them below depends on THIS statement, so nothing
+                //  the compiler schedules can read them while the load is in flight -- ADVICE r3)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qs[u & 1]), "+s"(ws[u & 1]) : : "memory");
                 if (u + 1 < 4) ham_sload(qs[(u + 1) & 1], ws[(u + 1) & 1], qbase + (size_t)(p + u + 1) * a.nq_pad, a.wq + p + u + 1);
                 const u32x16& q = qs[u & 1];
                 const uint32_t w = ws[u & 1];

@@ -188,3 +188,83 @@ def test_hamming_candidate_lists_are_compacted_before_they_overflow(N):
     np.testing.assert_array_equal(i[:64], oi)
     np.testing.assert_array_equal(d[:64], od)
     ix.close()
+
+
+def test_hamming_distance_rows_in_device_memory(N):
+    """sknnr_hamming_distances with device pointers (rows selected by a device index list, results left on the device)."""
+    import ctypes
+
+    import torch
+    from scipy.spatial.distance import cdist
+
+    rng = np.random.default_rng(6)
+    ref = rng.integers(0, 5, (300, 21)).astype(np.float64)
+    q = rng.integers(0, 5, (40, 21)).astype(np.float64)
+    w = rng.random(21) + 0.1
+    ix = N.Index(ref)
+    ix.set_hamming_weights(w)
+    rows = torch.tensor([3, 39, 0, 3], dtype=torch.int64, device="cuda")
+    qd = torch.as_tensor(q, device="cuda")
+    out = torch.empty((4, 300), dtype=torch.float64, device="cuda")
+    vp = ctypes.c_void_p
+    N.check(N.load().sknnr_hamming_distances(ix.handle, vp(qd.data_ptr()), 40, vp(rows.data_ptr()), 4, vp(out.data_ptr()), N.MEM_DEVICE,
+                                             vp(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), cdist(q[[3, 39, 0, 3]], ref, "hamming", w=w))
+    with pytest.raises(N.HipBackendError, match="set_hamming_weights"):
+        N.Index(ref).hamming_distances_host(q)
+    ix.close()
+
+
+@pytest.mark.parametrize("weights", ["uniform", "distance"])
+def test_numpy_tie_policy_through_raw_regressor_cuda_tensors_and_predict(weights):
+    """hamming_tie_policy("numpy") on tie-saturated node ids (three ids, integer weights): kneighbors of numpy rows and of
+    CUDA tensors, predict with uniform / inverse-distance weights and the X=None path equal scikit-learn's brute Hamming
+    regressor followed by the reference's reorder (REF _base.py:166-175) -- the reference's own pipeline."""
+    import torch
+    from sklearn.neighbors import KNeighborsRegressor
+
+    import sknnr_amd
+
+    rng = np.random.default_rng(12)
+    ref = rng.integers(0, 3, (400, 12)).astype(np.float64)
+    q = rng.integers(0, 3, (150, 12)).astype(np.float64)
+    y = rng.standard_normal((400, 3))
+    w = rng.integers(1, 4, 12).astype(np.float64)
+
+    def reference(X, k=4):
+        skl = KNeighborsRegressor(n_neighbors=k, algorithm="brute", metric="hamming", metric_params={"w": w}, weights=weights).fit(ref, y)
+        d, i = skl.kneighbors(X)
+        rounded = np.round(d / np.maximum(d.max(axis=1, keepdims=True), 1.0), decimals=10)
+        order = np.lexsort((i, np.abs(i - np.arange(len(i))[:, None]), rounded), axis=1)
+        d, i = np.take_along_axis(d, order, axis=1), np.take_along_axis(i, order, axis=1)
+        # the reference's predict = sklearn's predict over ITS kneighbors (the reordered ones)
+        if weights == "uniform":
+            pred = y[i].mean(axis=1)
+        else:
+            with np.errstate(divide="ignore"):
+                wt = 1.0 / d
+            inf = np.isinf(wt)
+            rows_inf = inf.any(axis=1)
+            wt[rows_inf] = inf[rows_inf]
+            pred = (y[i] * wt[:, :, None]).sum(axis=1) / wt.sum(axis=1)[:, None]
+        return d, i, pred
+
+    with sknnr_amd.hamming_tie_policy("numpy"):
+        est = sknnr_amd.RawKNNRegressor(n_neighbors=4, algorithm="brute", metric="hamming", metric_params={"w": w}, weights=weights)
+        est.fit(ref, y)
+        rd, ri, rp = reference(q)
+        d, i = est.kneighbors(q)
+        np.testing.assert_array_equal(i, ri)
+        np.testing.assert_array_equal(d, rd)
+        assert est.regressor_._last_numpy_tie_rows > 50 if hasattr(est, "regressor_") else est._last_numpy_tie_rows > 50
+        dt, it = est.kneighbors(torch.as_tensor(q, device="cuda"))
+        np.testing.assert_array_equal(it.cpu().numpy(), ri)
+        np.testing.assert_allclose(est.predict(q), rp, rtol=1e-12, atol=1e-12)
+        sd, si, sp = reference(None)
+        d, i = est.kneighbors()
+        np.testing.assert_array_equal(i, si)
+        np.testing.assert_allclose(est.independent_prediction_, sp, rtol=1e-12, atol=1e-12)
+    # the default policy differs on these inputs (lowest index first) -- the mode is what makes them equal
+    d0, i0 = est.kneighbors(q)
+    assert not np.array_equal(i0, ri)
