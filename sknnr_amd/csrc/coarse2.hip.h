@@ -74,7 +74,10 @@ __host__ __device__ constexpr int seed_tiles_for(long n_tiles, int tps) {
 }
 constexpr int kCoarse2Waves = SKNNR_V2_WAVES;
 constexpr int kCoarse2Nqb = 2;
-constexpr int kQueueCap = 5;      // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
+#ifndef SKNNR_V2_QCAP
+#define SKNNR_V2_QCAP 5
+#endif
+constexpr int kQueueCap = SKNNR_V2_QCAP;  // entries per lane and q-block in LDS ([entry][lane] 8-byte pairs)
 #ifndef SKNNR_V2_FLUSH_AT
 #define SKNNR_V2_FLUSH_AT 3
 #endif
@@ -358,13 +361,21 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
         const int off = below(b0) + 2 * below(b1) + 4 * below(b2);
         const int total = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
         // (reads and their wait in ONE statement: nothing may touch the destination registers while the data is in flight)
-        static_assert(kQueueCap == 5, "five entries per lane are read here");
-        unsigned long long own[kQueueCap];
-        asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:512\n\tds_read_b64 %2, %5 offset:1024\n\t"
-                     "ds_read_b64 %3, %5 offset:1536\n\tds_read_b64 %4, %5 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(own[0]), "=&v"(own[1]), "=&v"(own[2]), "=&v"(own[3]), "=&v"(own[4])
-                     : "v"(qbase + (unsigned)lane * 8u)
-                     : "memory");
+        static_assert(kQueueCap == 5 || kQueueCap == 4, "four or five entries per lane are read here");
+        unsigned long long own[5];
+        if constexpr (kQueueCap == 5) {
+            asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:512\n\tds_read_b64 %2, %5 offset:1024\n\t"
+                         "ds_read_b64 %3, %5 offset:1536\n\tds_read_b64 %4, %5 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(own[0]), "=&v"(own[1]), "=&v"(own[2]), "=&v"(own[3]), "=&v"(own[4])
+                         : "v"(qbase + (unsigned)lane * 8u)
+                         : "memory");
+        } else {
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
+                         "ds_read_b64 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(own[0]), "=&v"(own[1]), "=&v"(own[2]), "=&v"(own[3])
+                         : "v"(qbase + (unsigned)lane * 8u)
+                         : "memory");
+        }
 #pragma unroll
         for (int j = 0; j < kQueueCap; ++j) {
             // (pos < 2^26: the image is addressed with 32-bit offsets, use_coarse2) -- the column rides in the top bits
