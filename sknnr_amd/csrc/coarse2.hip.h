@@ -339,7 +339,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
     };
 
     // ---- wave flush (round 4): the entries of ALL lanes compacted, corrected 32 per trip, then inserted by their owners ----
-    // The pair flush below corrects the entries of a query's two lanes two per trip: a flush is triggered by ONE lane holding
+    // The pair flush of round 3 corrected the entries of a query's two lanes two per trip: a flush is triggered by ONE lane holding
     // kQueueFlushAt entries while the wave holds ~22 on 64 lanes, so it takes 2-3 trips of two dependent L2 round trips each
     // with 8-11 lanes at work (8,800 wave-cycles per flush, profiles/r03_coarse_timers.txt).  Here every lane first moves its
     // entries to consecutive slots of the queue region (prefix sum of the counts; DS operations of a wave execute in order:
@@ -347,7 +347,7 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
     // K halves) corrects entry 32 t + p whatever column it belongs to -- the column's hi / lo fragments come from the row's
     // own cache line of the query image, the row's fragments from the reference image, ALL of it one round of independent
     // loads -- and writes the corrected value back; finally every lane walks its own entries (now corrected) into its list.
-    // The corrected value is the same expression as in the pair flush (main + (lo.hi + hi.lo over K half 0 + K half 1));
+    // The corrected value is the same expression as in that flush (main + (lo.hi + hi.lo over K half 0 + K half 1));
     // which list an entry goes to does not matter to the certificate.  One L2 round trip per 32 entries instead of four to six.
     auto flush_wave = [&](int qb) {
         TSTAMP(1);
