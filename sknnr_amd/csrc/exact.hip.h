@@ -66,7 +66,18 @@ struct PrepArgs {
                            // (SKL/utils/validation.py _assert_all_finite, reached from SKL/neighbors/_base.py:838-845)
     CellTreeDev tree;      // query bucketing (bucket.hip.h): the register-resident kernel also names every row's cell
     unsigned char* cell;   // (nq) out, or null
+    int lds_wave_bytes;    // prep_queries_direct_kernel: the wave-private LDS region (prep_direct_wave_lds)
 };
+
+// prep_queries_direct_kernel's wave-private LDS tile (round 4): the transformed rows (since round 1) and the image rows of
+// the wave's 64 queries are transposed in it, so that every store instruction writes whole KiB of the (contiguous) output
+// instead of 16 bytes into each of 64 cache lines; rows sit 16 bytes apart from a power of two (conflict-free 16-byte
+// accesses).  (Staging the INPUT rows the same way was built and measured: prep 2.2 -> 4.2 ms -- the tile of 17 KB per wave
+// halves the occupancy and the reads through it cost more than the partial-line fetches they replace; not kept.)
+__host__ __device__ constexpr int prep_direct_wave_lds(int ks, bool has_xt, bool has_img) {
+    const int xt_b = has_xt ? 64 * (8 * ks + 1) * 8 : 0, img_b = has_img ? 64 * (64 * ks + 16) : 0;
+    return xt_b > img_b ? xt_b : img_b;
+}
 
 // |b| at or above this has no finite f16 image (65504 is the largest f16; the margin keeps hi + lo exact)
 constexpr double kImageLimit = 32768.0;
@@ -175,18 +186,20 @@ __global__ void __launch_bounds__(BT) prep_queries_kernel(PrepArgs a) {
 template <int KS>
 __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
     constexpr int DP = 16 * KS;
+    extern __shared__ __attribute__((aligned(16))) char prep_lds[];
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const bool live = q < a.nq;
+    const int lane_ = threadIdx.x & 63;
+    char* wtile = prep_lds + (size_t)(threadIdx.x >> 6) * a.lds_wave_bytes;  // this wave's region: input rows, then output tiles
     double acc[DP];
 #pragma unroll
     for (int j = 0; j < DP; ++j) acc[j] = 0.0;
     bool has_nan = false, has_inf = false;
-    if (live) {
-        const long xe = q * a.d_in;  // first element of the row
+    auto transform_row = [&](const void* xb, long xe) {
         if (a.proj) {
             int c = 0;
             if ((a.d_in & 1) == 0 && a.x_dtype == kDtypeF64) {
-                const double2* x2 = (const double2*)((const double*)a.x + xe);
+                const double2* x2 = (const double2*)((const double*)xb + xe);
                 for (; c < a.d_in; c += 2) {
                     const double2 xv = x2[c >> 1];
                     double v0 = xv.x, v1 = xv.y;
@@ -202,7 +215,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
                 }
             }
             for (; c < a.d_in; ++c) {
-                double v = load_as_f64(a.x, a.x_dtype, xe + c);
+                double v = load_as_f64(xb, a.x_dtype, xe + c);
                 classify(v, has_nan, has_inf);
                 if (a.center) v = v - a.center[c];
                 if (a.scale) v = v / a.scale[c];
@@ -214,7 +227,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
 #pragma unroll
             for (int k = 0; k < DP; ++k) {
                 if (k < a.d) {
-                    double v = load_as_f64(a.x, a.x_dtype, xe + k);
+                    double v = load_as_f64(xb, a.x_dtype, xe + k);
                     classify(v, has_nan, has_inf);
                     if (a.center) v = v - a.center[k];
                     if (a.scale) v = v / a.scale[k];
@@ -222,7 +235,8 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
                 }
             }
         }
-    }
+    };
+    if (live) transform_row(a.x, q * a.d_in);
     report_nonfinite(a.status, has_nan, has_inf);
     if (a.cell && live) {
         // cell of the row in the tree over the reference rows' principal axes: float32, on the transformed values at hand
@@ -245,8 +259,7 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
         // passes) so that every store instruction writes whole 64..128-byte row segments instead of
         // 64 scattered 8-byte words.  DS operations of one wave execute in order: no barrier.
         constexpr int HC = 8 * KS;
-        __shared__ double tile_all[4][64 * (HC + 1)];
-        double* tile = tile_all[threadIdx.x >> 6];
+        double* tile = (double*)wtile;  // (the input rows are in registers by now)
         const int lane = threadIdx.x & 63;
         const long q0 = q - lane;
 #pragma unroll
@@ -278,10 +291,27 @@ __global__ void __launch_bounds__(256) prep_queries_direct_kernel(PrepArgs a) {
             hi[jj] = h;
             lo[jj] = (_Float16)(float)(b - (double)h);
         }
-        if (q < a.nq_pad) {
+        {
+            // the image row (64 KS bytes: [hi | lo][K-step][K half] 16-byte pieces) into the wave's tile, rows 16 bytes apart
+            // from a power of two; the 64 image rows of the wave are contiguous in memory and go out below
             const int step = jc >> 1, hh = jc & 1;
-            a.qimg[qimg_index(q, 0, KS, step, hh)] = __builtin_bit_cast(uint4, hi);
-            a.qimg[qimg_index(q, 1, KS, step, hh)] = __builtin_bit_cast(uint4, lo);
+            char* irow = wtile + (size_t)lane_ * (64 * KS + 16);
+            *(uint4*)(irow + 16 * (int)qimg_index(0, 0, KS, step, hh)) = __builtin_bit_cast(uint4, hi);
+            *(uint4*)(irow + 16 * (int)qimg_index(0, 1, KS, step, hh)) = __builtin_bit_cast(uint4, lo);
+        }
+    }
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int PPR = 4 * KS;  // 16-byte pieces per image row
+        const long q0w = q - lane_;   // (a multiple of 64; the launch covers nq_pad rows, a multiple of the block)
+        uint4* dst = a.qimg + (size_t)q0w * PPR;
+#pragma unroll
+        for (int i = 0; i < PPR; ++i) {
+            const int p = 64 * i + lane_;
+            const int r = p / PPR, o = p % PPR;
+            dst[p] = *(const uint4*)(wtile + (size_t)r * (64 * KS + 16) + 16 * o);
         }
     }
     if (a.qnc && q < a.nq_pad) a.qnc[q] = live ? (overflow ? INFINITY : qn) : 0.0;

@@ -1,6 +1,9 @@
 // k_exact.hip -- kernel translation unit: query preparation, bucketing, finaliser, exact scan / merge, predict and the
 // small gather kernels (exact.hip.h, bucket.hip.h), behind the launchers of launch.hip.h.
 #define SKNNR_KERNELS_EXACT 1  // this unit defines the non-template kernels of exact.hip.h and bucket.hip.h
+#include <cstdint>
+#include <cstdlib>
+
 #include "launch.hip.h"
 
 namespace sknnr {
@@ -33,16 +36,24 @@ hipError_t row_norms(const double* x, long n, int d, double* out, hipStream_t st
     return hipGetLastError();
 }
 
-hipError_t prep_direct(const PrepArgs& a, hipStream_t st) {
-    const dim3 grid((unsigned)(a.nq_pad / 256)), block(256);
-    switch (a.ks) {
-        case 1: prep_queries_direct_kernel<1><<<grid, block, 0, st>>>(a); break;
-        case 2: prep_queries_direct_kernel<2><<<grid, block, 0, st>>>(a); break;
-        case 3: prep_queries_direct_kernel<3><<<grid, block, 0, st>>>(a); break;
-        case 4: prep_queries_direct_kernel<4><<<grid, block, 0, st>>>(a); break;
-        default: return hipErrorInvalidValue;
-    }
+template <int KS>
+hipError_t prep_direct_ks(PrepArgs a, hipStream_t st) {
+    a.lds_wave_bytes = prep_direct_wave_lds(KS, a.xt != nullptr, a.qimg != nullptr);
+    const size_t sh = (size_t)4 * a.lds_wave_bytes;
+    hipError_t e = hipFuncSetAttribute((const void*)prep_queries_direct_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return e;
+    prep_queries_direct_kernel<KS><<<dim3((unsigned)(a.nq_pad / 256)), dim3(256), sh, st>>>(a);
     return hipGetLastError();
+}
+
+hipError_t prep_direct(const PrepArgs& a, hipStream_t st) {
+    switch (a.ks) {
+        case 1: return prep_direct_ks<1>(a, st);
+        case 2: return prep_direct_ks<2>(a, st);
+        case 3: return prep_direct_ks<3>(a, st);
+        case 4: return prep_direct_ks<4>(a, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t prep_lds(int rows_per_block, const PrepArgs& a, hipStream_t st) {
