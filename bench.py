@@ -469,7 +469,10 @@ def main():
     if args.traffic in ("auto", "measure") and world_env == 1 and not args.force_dist and not args.traffic_child:
         import shutil
 
-        if args.traffic == "measure" or shutil.which("rocprofv3"):
+        under_profiler = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if under_profiler and args.traffic == "auto":
+            measured_note = "this run is itself under a profiler: no nested counter passes"
+        elif args.traffic == "measure" or shutil.which("rocprofv3"):
             measured, measured_note = measure_traffic(args, argv)
     # Libraries print to stdout (RCCL's version banner at communicator creation, for one): the contract is ONE JSON line
     # there, so file descriptor 1 points at stderr until that line is written.
