@@ -275,3 +275,46 @@ def test_hamming_tie_policy_setting():
     assert sknnr_amd.get_hamming_tie_policy() == "lowest_index"
     with pytest.raises(ValueError, match="must be one of"):
         sknnr_amd.set_hamming_tie_policy("scalar")
+
+
+def test_bench_counts_hbm_traffic_from_counter_passes(tmp_path, monkeypatch):
+    """bench.py --traffic: the two `rocprofv3 --pmc` child passes (FETCH_SIZE, WRITE_SIZE -- counters only, no trace domain on
+    the command line) and their reduction: KiB -> bytes, FETCH_SIZE doubled for the pre-filter only, per bulk launch of the
+    dominant kernel and per step.  A stub `rocprofv3` on PATH writes the CSVs a real pass would."""
+    import importlib.util
+    import stat
+    import sys
+
+    stub = tmp_path / "rocprofv3"
+    stub.write_text(
+        "#!/bin/bash\n"
+        'echo "$@" >> "%s/calls.txt"\n' % tmp_path +
+        'while [ $# -gt 0 ]; do case "$1" in --pmc) c=$2; shift 2;; -d) d=$2; shift 2;; --) break;; *) shift;; esac; done\n'
+        'mkdir -p "$d/host/1"\n'
+        'f="$d/host/1/9_counter_collection.csv"\n'
+        'echo "Dispatch_Id,Kernel_Name,Grid_Size,Counter_Name,Counter_Value" > "$f"\n'
+        'for i in 1 2 3 4; do\n'
+        '  if [ "$c" = FETCH_SIZE ]; then v=1000; w=300; else v=100; w=700; fi\n'
+        '  echo "$i,\\"void sknnr::coarse2_kernel<2, 6, 16, 0>(char const*)\\",9961472,$c,$v" >> "$f"\n'
+        '  echo "$i,\\"void sknnr::coarse2_kernel<2, 6, 4, 0>(char const*)\\",40960,$c,10" >> "$f"\n'
+        '  echo "$i,sknnr::prep_queries_direct_kernel<2>(sknnr::PrepArgs),10000128,$c,$w" >> "$f"\n'
+        '  echo "$i,at::native::some_torch_kernel,64,$c,99999" >> "$f"\n'
+        "done\n")
+    stub.chmod(stub.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", f"{tmp_path}:{os.environ['PATH']}")
+    spec = importlib.util.spec_from_file_location("bench_module_traffic", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["--rows", "123456", "--steps", "30", "--traffic", "measure", "--no-extras"]
+    got, note = bench.measure_traffic(bench.parse_args(argv), argv)
+    assert got["steps_counted"] == 4
+    assert got["dominant_bytes_per_launch"] == (2 * 1000 + 100) * 1024          # FETCH x2 + WRITE, KiB -> bytes
+    per_step = (2 * 1000 + 100) + (2 * 10 + 10) + (300 + 700)                   # both pre-filter launches doubled, prep as read
+    assert got["step_bytes"] == per_step * 1024
+    assert "counted in this run" in note
+    calls = open(tmp_path / "calls.txt").read().splitlines()
+    assert len(calls) == 2 and all("--pmc" in c and "trace" not in c.split(" -- ")[0] for c in calls)
+    child = calls[0].split(" -- ")[1].split()
+    assert child[0] == sys.executable and child[1].endswith("bench.py")
+    assert "--traffic off" in calls[0] and "--traffic-child" in calls[0] and "--rows 123456" in calls[0]
+    assert "--steps 3" in calls[0] and "--steps 30" not in calls[0]
