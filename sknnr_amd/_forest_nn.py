@@ -26,7 +26,7 @@ class WeightedTreesNNRegressor(YFitMixin, TransformedKNeighborsRegressor):
     """Base of the tree-node regressors: brute-force search under the Hamming metric with one weight per
     tree = the transformer's tree weight x the forest's weight / trees per boosting iteration.
 
-    Exactly tied rows: distances are bit-identical to the reference's (scipy's ``cdist(..., "hamming", w=w)``).  Among
+    Exactly tied rows: distances are bit-identical to the reference's (scipy's weighted Hamming distance, summed in tree order).  Among
     reference rows tied EXACTLY at the k-th distance the device keeps the lowest index first; the reference keeps what
     ``np.argpartition`` keeps (REF src/sknnr/_weighted_trees.py:53-59 -> SKL/neighbors/_base.py:733-760).  For the
     reference's own choice -- its committed RFNN / GBNN regression files are then matched row for row -- fit and query
