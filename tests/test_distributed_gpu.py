@@ -123,3 +123,82 @@ def test_bench_force_dist_single_rank():
     assert res["roofline"]["timed_calls"] == 2 * 3  # three gather chunks per step (--gather-chunks; default two), all summed
     assert 0 < res["roofline"]["frac"] <= 1.0
     assert res["parity_vs_cpu_reference"]["index_rows_equal"] == res["parity_vs_cpu_reference"]["rows"]
+
+
+def _gloo_worker(rank, world, port, out_dir):
+    """Two (three) ranks on ONE GPU: every rank's engine lives on cuda:0, the collectives run over gloo on host tensors.
+    RCCL refuses several ranks per device, so this is how the N > 1 ENGINE paths (not the RCCL transport) run on the
+    one-GPU box: query-row shards, the X=None shards, reference-row shards with the device merge, the Hamming metric."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sknnr_amd
+        from sknnr_amd import synth
+        from sknnr_amd.distributed import RefShardedKNN, ShardedKNN
+
+        x_ref, y, x_q = synth.make_problem(6000, 9001, 12, t=3, kind="positive", n_dup_queries=16)
+        x_ref[3100] = x_ref[100]  # duplicates on both sides of the reference-shard boundaries: ties across shards
+        x_ref[5100] = x_ref[100]
+        x_q[1] = x_q[0]
+        est = sknnr_amd.GNNRegressor(n_neighbors=4, weights="distance").fit(x_ref, y)
+        sh = ShardedKNN(est)
+        d_all, i_all = sh.kneighbors(x_q, 4)
+        d_self, i_self = sh.kneighbors(None, 4)
+        p_all = sh.predict(x_q)
+        rs = RefShardedKNN(est)
+        d_ref, i_ref = rs.kneighbors(x_q[:3000], 4)
+        d_rself, i_rself = rs.kneighbors(None, 4)
+        # the tree-node family: node ids from the host transformer, weighted Hamming on the device, both shardings
+        ids_ref, ids_q = synth.make_forest_ids(3000, 500, 40, seed=5)
+        w = np.random.default_rng(1).random(40) + 0.05
+        ham = sknnr_amd.RawKNNRegressor(n_neighbors=3, algorithm="brute", metric="hamming", metric_params={"w": w}).fit(ids_ref, ids_ref[:, :2])
+        hd, hi = ShardedKNN(ham).kneighbors(ids_q, 3)
+        hrd, hri = RefShardedKNN(ham).kneighbors(ids_q, 3)
+        hsd, hsi = RefShardedKNN(ham).kneighbors(None, 3)
+        try:
+            rs.kneighbors(x_q[:10], 6000 // world + 1)
+            refused = False
+        except ValueError:
+            refused = True
+        np.savez(os.path.join(out_dir, f"gloo_rank{rank}.npz"), d_all=d_all, i_all=i_all, d_self=d_self, i_self=i_self, p_all=p_all,
+                 d_ref=d_ref, i_ref=i_ref, d_rself=d_rself, i_rself=i_rself, hd=hd, hi=hi, hrd=hrd, hri=hri, hsd=hsd, hsi=hsi,
+                 refused=np.asarray(refused))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_on_one_gpu_drive_the_engine_paths(tmp_path, world):
+    """the multi-rank estimator / engine paths of ShardedKNN and RefShardedKNN -- Hamming and X=None
+    included -- on hardware, results equal to the single call on every rank."""
+    import torch.multiprocessing as mp
+
+    import sknnr_amd
+    from sknnr_amd import synth
+
+    mp.spawn(_gloo_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    x_ref, y, x_q = synth.make_problem(6000, 9001, 12, t=3, kind="positive", n_dup_queries=16)
+    x_ref[3100] = x_ref[100]
+    x_ref[5100] = x_ref[100]
+    x_q[1] = x_q[0]
+    est = sknnr_amd.GNNRegressor(n_neighbors=4, weights="distance").fit(x_ref, y)
+    d, i = est.kneighbors(x_q)
+    ds, is_ = est.kneighbors()
+    p = est.predict(x_q)
+    ids_ref, ids_q = synth.make_forest_ids(3000, 500, 40, seed=5)
+    w = np.random.default_rng(1).random(40) + 0.05
+    ham = sknnr_amd.RawKNNRegressor(n_neighbors=3, algorithm="brute", metric="hamming", metric_params={"w": w}).fit(ids_ref, ids_ref[:, :2])
+    hd, hi = ham.kneighbors(ids_q)
+    hsd, hsi = ham.kneighbors()
+    for rank in range(world):
+        r = np.load(os.path.join(str(tmp_path), f"gloo_rank{rank}.npz"))
+        assert bool(r["refused"])
+        for got, want in ((r["i_all"], i), (r["d_all"], d), (r["i_self"], is_), (r["d_self"], ds), (r["p_all"], p),
+                          (r["i_ref"], i[:3000]), (r["d_ref"], d[:3000]), (r["i_rself"], is_), (r["d_rself"], ds),
+                          (r["hi"], hi), (r["hd"], hd), (r["hri"], hi), (r["hrd"], hd), (r["hsi"], hsi), (r["hsd"], hsd)):
+            np.testing.assert_array_equal(got, want)
