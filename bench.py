@@ -68,6 +68,9 @@ def parse_args(argv=None):
                          "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (counters only, no trace domains) before this process "
                          "touches the GPU; 'auto' does so at N = 1 when rocprofv3 is on PATH, else quotes the committed passes")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: 'nccl' = RCCL over xGMI, one rank per GPU (the measured configuration); 'gloo' rehearses the "
+                         "same step with several ranks on ONE GPU (RCCL refuses that), collectives on CUDA tensors over gloo")
     ap.add_argument("--dry-launch", action="store_true",
                     help="--gpus N > 1 outside a launcher: print the command that would start the N ranks and exit")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (default: a free one)")
@@ -492,19 +495,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(1, torch.cuda.device_count())  # (--backend gloo: the ranks may share a GPU)
+    torch.cuda.set_device(device)
     import torch.distributed as dist
 
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from sknnr_amd.distributed import cyclic_slot
 
     # ---- fit (host, once): CCA ordination of the synthetic reference set -> affine map ------
-    eng, x_ref_t, affine, y_ref, t_fit = fit_space("gnn", args.refs, args.dims, args.targets, local_rank)
+    eng, x_ref_t, affine, y_ref, t_fit = fit_space("gnn", args.refs, args.dims, args.targets, device)
     center, _, proj = affine
     d_t = proj.shape[1]
 
@@ -641,7 +648,8 @@ def main():
                 "workload": f"GNN-style kneighbors: affine {args.dims}->{d_t} (CCA fit on synthetic refs) + "
                             f"{total_rows} query rows in total ({nq} per GPU, {args.scaling} scaling) x {args.refs} refs x "
                             f"{d_t} dims, k={k}, deterministic reorder, float64 (dist, idx) out"
-                            + (" + RCCL all-gather" if use_dist and not args.no_gather else ""),
+                            + ((" + RCCL all-gather" if args.backend == "nccl" else " + gloo all-gather (rehearsal: ranks share a GPU)")
+                               if use_dist and not args.no_gather else ""),
                 "total_rows": total_rows, "rows_per_gpu": nq, "n_ref": args.refs, "d_in": args.dims, "d_t": int(d_t), "k": k,
                 "parallelism": f"query-row shards x{world}",
             },
@@ -652,6 +660,19 @@ def main():
         }
         if use_dist:
             result["gather_in_place"] = gather_in_place[0]
+        if use_dist and not args.no_gather:
+            # The gathered arrays hold what the OTHER ranks computed: rank 0 regenerates the last rank's rows (seeded) and
+            # answers a prefix of its first gather chunk itself, at that block's global position -- equal bit for bit when
+            # every block sits where the chunk-cyclic layout says and every rank ran the same index.
+            r_chk = world - 1
+            q_r = q if r_chk == rank else gen_queries(nq, args.dims, 1000 + r_chk, torch)
+            a0, b0 = gather_chunks[0]
+            n_chk = min(20_000, b0 - a0)
+            lo = cyclic_slot(world, r_chk, a0, b0)
+            d_exp, i_exp = eng.kneighbors(q_r[a0:a0 + n_chk], k, apply_affine=True, deterministic=True, row_offset=lo)
+            result["gather_check"] = {"rank": r_chk, "rows": int(n_chk), "global_row": int(lo),
+                                      "equal": bool(torch.equal(i_out[lo:lo + n_chk], i_exp) and torch.equal(d_out[lo:lo + n_chk], d_exp))}
+            del q_r
         if world == 1 and not args.no_cpu_baseline:
             n_s = min(args.cpu_sample, nq)
             q_host = q[:n_s].cpu().numpy()
@@ -667,7 +688,7 @@ def main():
             result["speedup_vs_cpu"] = value / base["value"]
         if world == 1 and not args.no_extras and not use_dist:
             del d_out, i_out
-            result.update(extras(args, eng, q, x_ref_t, affine, torch, local_rank))
+            result.update(extras(args, eng, q, x_ref_t, affine, torch, device))
         emit(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()

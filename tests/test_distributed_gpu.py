@@ -119,7 +119,7 @@ def test_bench_force_dist_single_rank():
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["gather_in_place"] is True
+    assert res["gather_in_place"] is True and res["gather_check"]["equal"] is True
     assert res["roofline"]["timed_calls"] == 2 * 3  # three gather chunks per step (--gather-chunks; default two), all summed
     assert 0 < res["roofline"]["frac"] <= 1.0
     assert res["parity_vs_cpu_reference"]["index_rows_equal"] == res["parity_vs_cpu_reference"]["rows"]
@@ -202,3 +202,20 @@ def test_gloo_ranks_on_one_gpu_drive_the_engine_paths(tmp_path, world):
                           (r["i_ref"], i[:3000]), (r["d_ref"], d[:3000]), (r["i_rself"], is_), (r["d_rself"], ds),
                           (r["hi"], hi), (r["hd"], hd), (r["hri"], hi), (r["hrd"], hd), (r["hsi"], hsi), (r["hsd"], hsd)):
             np.testing.assert_array_equal(got, want)
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` as the driver types it -- the bench starts its own two ranks -- with `--backend gloo`, which
+    lets both ranks share the ONE GPU of the box (RCCL refuses that): the strong-scaling split, the chunk-cyclic in-place
+    all-gather on a side stream, the max-over-ranks timing and the parity check of the gathered result run with W = 2 on
+    hardware; only the transport differs from the measured configuration."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--rows", "2000000", "--gather-chunks", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["total_rows"] == 2_000_000
+    assert res["config"]["rows_per_gpu"] == 1_000_000 and "gloo" in res["config"]["workload"]
+    assert res["roofline"]["timed_calls"] == 2 * 3 and 0 < res["roofline"]["frac"] <= 1.0
+    assert res["gather_check"]["rank"] == 1 and res["gather_check"]["rows"] > 0 and res["gather_check"]["equal"] is True
