@@ -303,9 +303,9 @@ def measure_traffic(args, argv):
             env = dict(os.environ, TMPDIR="/tmp")
             try:
                 proc = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", *child],
-                                      capture_output=True, text=True, timeout=420, env=env, cwd="/tmp")
+                                      capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
             except subprocess.TimeoutExpired:
-                return None, f"the {counter} pass did not finish in 420 s"
+                return None, f"the {counter} pass did not finish in 180 s"
             if proc.returncode != 0:
                 return None, f"the {counter} pass failed (rc {proc.returncode}): {proc.stderr[-300:]}"
             rows = []
