@@ -301,13 +301,23 @@ def measure_traffic(args, argv):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, counter)
             env = dict(os.environ, TMPDIR="/tmp")
+            # (a process group of its own: a pass that overruns is ended with everything it started -- nothing of it may
+            #  still be on the GPU when the timed region of this process begins)
+            proc = subprocess.Popen([rocprof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", *child],
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp", start_new_session=True)
             try:
-                proc = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", *child],
-                                      capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
+                _, err = proc.communicate(timeout=180)
             except subprocess.TimeoutExpired:
+                import signal
+
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.communicate()
                 return None, f"the {counter} pass did not finish in 180 s"
             if proc.returncode != 0:
-                return None, f"the {counter} pass failed (rc {proc.returncode}): {proc.stderr[-300:]}"
+                return None, f"the {counter} pass failed (rc {proc.returncode}): {err[-300:]}"
             rows = []
             for f in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
                 rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "sknnr" in r["Kernel_Name"]]
