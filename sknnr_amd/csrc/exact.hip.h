@@ -586,6 +586,10 @@ __device__ __forceinline__ bool group_any(bool flag, int gbase) {
 // (measured per 10M rows: forcing 8 waves per SIMD on the 12-candidate instantiation -- 64 VGPRs, 68 bytes of scratch --
 // takes 8.0 ms instead of 4.5; collapsing the row gathers to one row per query saves 0.3 ms; dropping the index
 // tie-break from the ranking loop saves nothing: the compiler's 80 VGPRs / 6 waves stay)
+// LDS row of one group's query in finalize_kernel: 16 bytes of padding spread the groups of a wave over the banks
+__host__ __device__ constexpr size_t finalize_row_bytes(int d) { return (size_t)d * 8 + 16; }
+__host__ __device__ constexpr size_t finalize_lds_bytes(int m_tmpl, int d) { return (size_t)(256 / (2 * m_tmpl)) * finalize_row_bytes(d); }
+
 template <int M>
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     constexpr int LPQ = 2 * M;
@@ -596,6 +600,16 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const bool live = q < s.nq;
     if (!live) q = s.nq - 1;  // keep the lane for the exchanges; it writes nothing
     if (a.qperm) q = a.qperm[a.pos0 + q];
+
+    // The query's float64 row, once per GROUP (round 4): every lane of the group re-scores one candidate against the same
+    // row, and sixteen lanes fetching the same 256 bytes cost the vector cache as much as sixteen different rows.  The
+    // group's lanes load the row together (8 bytes each per trip) into LDS and read it from there.
+    extern __shared__ __attribute__((aligned(16))) char fin_lds[];
+    double* xrow = (double*)(fin_lds + (size_t)(threadIdx.x / LPQ) * finalize_row_bytes(s.d));
+    for (int e = c; e < s.d; e += LPQ) xrow[e] = s.xq[q * s.d + e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (a group lies inside one wave; DS operations of a wave execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     const int list = c / M, slot = c % M;
     const bool has_slot = slot < a.m_list;
@@ -624,7 +638,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const bool need = valid && ((double)cv <= tau_c + 2.0 * eps + 2.0 * noise * a.s2);
 
     double d2 = INFINITY;
-    if (need) d2 = pair_d2(s.xq + q * s.d, s.ref + (long)id * s.d, s.d, s.rn[id], s.formula);
+    if (need) d2 = pair_d2(xrow, s.ref + (long)id * s.d, s.d, s.rn[id], s.formula);
     const bool usable = need && (d2 == d2) && d2 < INFINITY;
     if (!usable) d2 = INFINITY;
     const int key_id = usable ? id : (0x7fffff00 + c);  // unusable slots sort last, distinct
