@@ -89,11 +89,16 @@ __host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb *
 #ifndef SKNNR_V2_M2
 #define SKNNR_V2_M2 1  // one neighbour (lists of 2) on the second-generation kernel, up to 32 features
 #endif
+#ifndef SKNNR_V2_M12
+#define SKNNR_V2_M12 1  // 16 .. 23 neighbours on pooled lists of 12 at ONE K-step, 16 waves (round 4: 98 -> 113 Mq/s at 16 features,
+                        // k = 20; at two K-steps the instance spills 20 registers and loses to lists of 16 at 12 waves, 65 vs 87 Mq/s)
+#endif
 #ifndef SKNNR_V2_M16
 #define SKNNR_V2_M16 1  // 8 .. 15 neighbours (lists of 16) on the second-generation kernel, up to 32 features, 12 waves
 #endif
 __host__ __device__ constexpr bool coarse2_supported(int ks, int m) {
-    return (m == 6 && ks <= 4) || (m == 8 && ks <= 3) || (SKNNR_V2_M2 && m == 2 && ks <= 2) || (SKNNR_V2_M16 && m == 16 && ks <= 2);
+    return (m == 6 && ks <= 4) || (m == 8 && ks <= 3) || (SKNNR_V2_M2 && m == 2 && ks <= 2) || (SKNNR_V2_M16 && m == 16 && ks <= 2) ||
+           (SKNNR_V2_M12 && m == 12 && ks <= 1);
 }
 // waves per workgroup of the bulk launch: 16 (4 per SIMD, <= 128 VGPRs); lists of 16 need 12 (3 per SIMD, <= 168)
 #ifndef SKNNR_V2_M16_WAVES
@@ -135,6 +140,7 @@ __device__ __forceinline__ float pair_union_rank(const float (&vals)[M]) {
 // Ranks beyond the length of a list (one kernel instance each), by neighbours searched (kk):
 //   lists of 6 : rank  9 for kk = 6 .. 7
 //   lists of 8 : rank 12 for kk = 8 .. 10, 15 for 11 .. 13, 16 (the whole pool) for 14 .. 15
+//   lists of 12: rank 22 for kk = 16 .. 20, 24 (the whole pool) for 21 .. 23
 //   lists of 16: rank 22 for kk = 16 .. 20, 27 for 21 .. 25, 31 for 26 .. 30, 32 for 31
 // A rank above kk + 1 is a looser threshold, never a wrong one, and the certificate likes the slack: the gaps between a
 // query's consecutive neighbour distances shrink with the rank.
@@ -142,9 +148,10 @@ __host__ __device__ constexpr int coarse2_rank_extra(int m_list, int kk) {
     if (kk + 1 <= m_list) return 0;
     if (m_list == 6) return 3;
     if (m_list == 8) return kk <= 10 ? 4 : (kk <= 13 ? 7 : 8);
+    if (m_list == 12) return kk <= 20 ? 10 : 12;
     return kk <= 20 ? 6 : (kk <= 25 ? 11 : (kk <= 30 ? 15 : 16));
 }
-constexpr int kCoarse2MaxKK6 = 7, kCoarse2MaxKK8 = 15;
+constexpr int kCoarse2MaxKK6 = 7, kCoarse2MaxKK8 = 15, kCoarse2MaxKK12 = 23;
 constexpr int kCoarse2MaxKK16 = 31;
 
 // The skip test of a unit: the minimum of its sixteen main values, as raw instructions (hipcc neither interleaves

@@ -1,6 +1,6 @@
 // k_coarse2.hip -- kernel translation unit: the second-generation MFMA pre-filter (coarse2.hip.h), one instance per
 // (K-steps, list length, waves per workgroup, rank beyond the list), behind launch.hip.h.  Compiled in two halves
-// (-DSKNNR_C2_PART=0: lists of 2 and 6; =1: lists of 8 and 16) so that the halves build in parallel.
+// (-DSKNNR_C2_PART=0: lists of 2 and 6; =1: lists of 8, 12 and 16) so that the halves build in parallel.
 #include <cstdio>
 #include <cstring>
 
@@ -38,6 +38,9 @@ int by_rank(int extra, const launch::Coarse2Launch& L, hipStream_t st, hipError_
         if (extra == 11) { *err = go<KS, M, WAVES, 11>(L, st); return 0; }
         if (extra == 15) { *err = go<KS, M, WAVES, 15>(L, st); return 0; }
         if (extra == 16) { *err = go<KS, M, WAVES, 16>(L, st); return 0; }
+    } else if constexpr (M == 12) {
+        if (extra == 10) { *err = go<KS, M, WAVES, 10>(L, st); return 0; }
+        if (extra == 12) { *err = go<KS, M, WAVES, 12>(L, st); return 0; }
     } else if constexpr (M == 8) {
         if (extra == 4) { *err = go<KS, M, WAVES, 4>(L, st); return 0; }
         if (extra == 7) { *err = go<KS, M, WAVES, 7>(L, st); return 0; }
@@ -111,6 +114,7 @@ int coarse2_part1(int ks, int m, int waves, int extra, const Coarse2Launch& L, h
     if (ks == 1 && m == 8) return by_waves<1, 8>(waves, extra, L, st, err);
     if (ks == 2 && m == 8) return by_waves<2, 8>(waves, extra, L, st, err);
     if (ks == 3 && m == 8) return by_waves<3, 8>(waves, extra, L, st, err);
+    if (ks == 1 && m == 12) return by_waves<1, 12>(waves, extra, L, st, err);
     if (ks == 1 && m == 16) return by_waves<1, 16>(waves, extra, L, st, err);
     if (ks == 2 && m == 16) return by_waves<2, 16>(waves, extra, L, st, err);
 #endif

@@ -1236,7 +1236,7 @@ constexpr int kCusPerDevice = 256;
 int launch_coarse2_waves(sknnr_index* ix, int m_list, int waves, long row0, long rows, int kk, hipStream_t st) {
     // more neighbours than a list holds: thresholds of rank M + E, no sentinels (coarse2_rank_extra)
     const int extra = coarse2_rank_extra(m_list, kk);
-    if (extra != 0 && !((m_list == 16 && kk <= kCoarse2MaxKK16) || (m_list == 8 && kk <= kCoarse2MaxKK8) || (m_list == 6 && kk <= kCoarse2MaxKK6)))
+    if (extra != 0 && !((m_list == 16 && kk <= kCoarse2MaxKK16) || (m_list == 12 && kk <= kCoarse2MaxKK12) || (m_list == 8 && kk <= kCoarse2MaxKK8) || (m_list == 6 && kk <= kCoarse2MaxKK6)))
         return fail(SKNNR_ERR_UNSUPPORTED, "lists of %d cannot serve %d neighbours", m_list, kk);
     // positions [row0, row0 + rows) of the chunk (bucketed calls: position -> row through qperm, else the row itself)
     const bool bucketed = ix->cell_depth > 0;
@@ -1312,18 +1312,19 @@ bool use_coarse2(const sknnr_index* ix, int m_list) {
 constexpr int kCoarseMaxKK = 31;
 int coarse_list_len(int kk) { return kk <= 1 ? 2 : (kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32))); }
 // ... for this handle: where the second-generation kernel serves them, 6 .. 7 neighbours keep lists of 6, 8 .. 15 lists of
-// 8 and 16 .. 31 lists of 16, with thresholds of a rank beyond one list over the two lists of a query kept as one pool
+// 8 and 16 .. 31 lists of 16 (16 .. 23 lists of 12 at one K-step), with thresholds of a rank beyond one list over the two lists of a query kept as one pool
 // (coarse2.hip.h, pair_union_rank, coarse2_rank_extra) -- shorter lists are cheaper to keep, lists of 8 run with 16 waves
 // per CU and no spills where lists of 16 need 12 waves, and lists of 32 exist on the first-generation kernel only.
 int coarse_list_len(const sknnr_index* ix, int kk) {
     static const int enabled = [] {
-        const char* e = std::getenv("SKNNR_V2_BIG_K");  // 0: off, 1: lists of 16 only, 2: and lists of 8, default: all
-        return e ? std::atoi(e) : 3;
+        const char* e = std::getenv("SKNNR_V2_BIG_K");  // 0: off, 1: lists of 16 only, 2: and lists of 8, 3: and 6 .. 7 on lists of 6, default: all
+        return e ? std::atoi(e) : 4;
     }();
     // (6 .. 7 neighbours: lists of 8 hold them where that kernel exists -- measured equal, 169 vs 169 Mq/s at 10M x 50k x 32,
     //  k = 7 -- and lists of 6 serve four K-steps, where lists of 8 would spill: 84 -> 95 Mq/s at 64 features)
     if (enabled >= 3 && kk > 5 && kk <= kCoarse2MaxKK6 && !use_coarse2(ix, 8) && use_coarse2(ix, 6)) return 6;
     if (enabled >= 2 && kk > 7 && kk <= kCoarse2MaxKK8 && use_coarse2(ix, 8)) return 8;
+    if (enabled >= 4 && kk > 15 && kk <= kCoarse2MaxKK12 && use_coarse2(ix, 12)) return 12;
     if (enabled >= 1 && kk > 15 && kk <= kCoarse2MaxKK16 && use_coarse2(ix, 16)) return 16;
     return coarse_list_len(kk);
 }
@@ -1446,7 +1447,8 @@ int run_device(sknnr_index* ix, const void* xdev, long nq, const sknnr_query_opt
     // after it reads (finaliser, exact scan), as it does for rows that go through the affine map
     const int x_dtype = self_rows ? kDtypeF64 : o->query_dtype;
     const bool to_xt = affine || x_dtype != kDtypeF64;
-    const bool coarse = ix->ks > 0 && kk <= kCoarseMaxKK && o->formula != SKNNR_FORMULA_HAMMING;
+    static const bool scan_everything = std::getenv("SKNNR_EXACT_ONLY") != nullptr;  // development: time the float64 scan alone
+    const bool coarse = ix->ks > 0 && kk <= kCoarseMaxKK && o->formula != SKNNR_FORMULA_HAMMING && !scan_everything;
     const int d_x = affine ? ix->d_in : ix->d;
     if (nq > 0x7fffffffL) return fail(SKNNR_ERR_UNSUPPORTED, "more than 2^31 - 1 query rows in one call");
     if (affine && ix->ks == 0)
