@@ -254,14 +254,9 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
     const int half = lane >> 5;
     const int qb0 = (blockIdx.x * WAVES + wave) * NQB;
     const unsigned qwave = lds_addr_of(smem + 2 * STAGE + wave * queue2_bytes_per_wave() + lane * 8);
-    // the row behind this lane's column of q-block qb: needed at the start, by every flush and at the end -- kept in LDS
+    // the row behind this lane's column of q-block qb: needed at the start and by every flush -- kept in LDS
     // (two registers more would spill), and the rotation of the sweep (workgroup-uniform)
     const unsigned qrow_lds = lds_addr_of(smem + 2 * STAGE + wave * queue2_bytes_per_wave() + NQB * kQueueCap * 512 + lane * 4);
-    auto qrow_of = [&](int qb) {
-        int r;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(qrow_lds + qb * 256) : "memory");
-        return r;
-    };
     int st0 = 0;
     if (qperm) {
         const int mid = qperm[pos0 + (blockIdx.x * WAVES + WAVES / 2) * NQB * 32];
@@ -589,7 +584,9 @@ coarse2_kernel(const char* __restrict__ rhi,    // n_stages * TPS records [hi: K
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         flush_wave(qb);
-        const size_t q = (size_t)qrow_of(qb);
+        // (the lists are filed under the POSITION of the chunk -- the row itself unless the call is bucketed: consecutive lanes
+        //  write consecutive lists, and the finaliser reads them without waiting for the position -> row table, round 4)
+        const size_t q = (size_t)(pos0 + (qb0 + qb) * 32 + (lane & 31));
         const size_t base = (q * 2 + half) * M;
         // a poisoned query (dropped hits) must fail the certificate: a NaN bound never certifies
         const int mine = loose[qb] != loose[qb] ? 1 : 0;

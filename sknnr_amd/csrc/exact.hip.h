@@ -613,6 +613,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const int c = (int)(gt % LPQ);
     const bool live = q < s.nq;
     if (!live) q = s.nq - 1;  // keep the lane for the exchanges; it writes nothing
+    // the candidate lists are filed by POSITION (coarse2.hip.h): read beside the position -> row table, not behind it
+    const long q_list = a.qperm ? a.pos0 + q : q;
     if (a.qperm) q = a.qperm[a.pos0 + q];
 
     // The query's float64 row, once per GROUP (round 4): every lane of the group re-scores one candidate against the same
@@ -627,7 +629,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 
     const int list = c / M, slot = c % M;
     const bool has_slot = slot < a.m_list;
-    const long cpos = (q * 2 + list) * a.m_list + (has_slot ? slot : 0);
+    const long cpos = (q_list * 2 + list) * a.m_list + (has_slot ? slot : 0);
     const int pos_img = has_slot ? a.cand_idx[cpos] : -1;
     const float cv = has_slot ? a.cand_val[cpos] : INFINITY;
     const bool valid = pos_img >= 0 && pos_img < s.n_ref;
