@@ -22,7 +22,11 @@ namespace sknnr {
 
 constexpr int kCellMaxDepth = 6;                 // up to 64 cells
 constexpr int kCellMax = 1 << kCellMaxDepth;
-constexpr int kBucketBlock = 1024;               // rows per block of the counting sort (one per thread)
+constexpr int kBucketBlock = 1024;               // threads per block of the counting sort
+#ifndef SKNNR_BUCKET_CHUNKS
+#define SKNNR_BUCKET_CHUNKS 32
+#endif
+constexpr int kBucketChunks = SKNNR_BUCKET_CHUNKS;  // rows per thread: a block sorts kBucketChunks x kBucketBlock rows
 
 // The tree: `depth` leading principal axes (unit vectors, [depth][d]), the centre they are taken about and the split
 // values, node `n` of level `l` at (1 << l) - 1 + n.  All in device memory.
@@ -94,8 +98,13 @@ __global__ void __launch_bounds__(kBucketBlock) cell_count_kernel(CellArgs a) {
     __shared__ int h[kCellMax];
     if (threadIdx.x < kCellMax) h[threadIdx.x] = 0;
     __syncthreads();
-    const long q = (long)blockIdx.x * kBucketBlock + threadIdx.x;
-    if (q < a.nq) atomicAdd(&h[a.cell[q]], 1);
+    // (kBucketChunks x 1024 rows per block: the 64 device-wide counters take one atomic per block and cell -- with one chunk per
+    //  block those 625k atomics on 64 addresses were the kernel's time at 10M rows)
+#pragma unroll
+    for (int r = 0; r < kBucketChunks; ++r) {
+        const long q = ((long)blockIdx.x * kBucketChunks + r) * kBucketBlock + threadIdx.x;
+        if (q < a.nq) atomicAdd(&h[a.cell[q]], 1);
+    }
     __syncthreads();
     if (threadIdx.x < kCellMax && h[threadIdx.x] != 0) atomicAdd(&a.hist[threadIdx.x], h[threadIdx.x]);
 }
@@ -118,19 +127,28 @@ __global__ void __launch_bounds__(kBucketBlock) cell_scatter_kernel(CellArgs a) 
         }
     }
     __syncthreads();
-    const long q = (long)blockIdx.x * kBucketBlock + threadIdx.x;
-    int c = 0, ticket = 0;
-    if (q < a.nq) {
-        c = a.cell[q];
-        ticket = atomicAdd(&cnt[c], 1);
-    } else if (q < a.n_pad) {
-        a.perm[q] = (int)q;  // padding rows keep their place behind the live ones
-        a.cell[q] = (unsigned char)(n_cells - 1);
+    int c[kBucketChunks], ticket[kBucketChunks];
+#pragma unroll
+    for (int r = 0; r < kBucketChunks; ++r) {
+        const long q = ((long)blockIdx.x * kBucketChunks + r) * kBucketBlock + threadIdx.x;
+        c[r] = 0;
+        ticket[r] = 0;
+        if (q < a.nq) {
+            c[r] = a.cell[q];
+            ticket[r] = atomicAdd(&cnt[c[r]], 1);
+        } else if (q < a.n_pad) {
+            a.perm[q] = (int)q;  // padding rows keep their place behind the live ones
+            a.cell[q] = (unsigned char)(n_cells - 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x < kCellMax && cnt[threadIdx.x] != 0) base[threadIdx.x] = atomicAdd(&a.hist[kCellMax + threadIdx.x], cnt[threadIdx.x]);
     __syncthreads();
-    if (q < a.nq) a.perm[first[c] + base[c] + ticket] = (int)q;
+#pragma unroll
+    for (int r = 0; r < kBucketChunks; ++r) {
+        const long q = ((long)blockIdx.x * kBucketChunks + r) * kBucketBlock + threadIdx.x;
+        if (q < a.nq) a.perm[first[c[r]] + base[c[r]] + ticket[r]] = (int)q;
+    }
 }
 #endif  // SKNNR_KERNELS_EXACT
 

@@ -76,11 +76,11 @@ hipError_t cell_assign(const CellArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t cell_count(const CellArgs& a, hipStream_t st) {
-    cell_count_kernel<<<dim3((unsigned)((a.nq + kBucketBlock - 1) / kBucketBlock)), dim3(kBucketBlock), 0, st>>>(a);
+    cell_count_kernel<<<dim3((unsigned)((a.nq + kBucketBlock * kBucketChunks - 1) / (kBucketBlock * kBucketChunks))), dim3(kBucketBlock), 0, st>>>(a);
     return hipGetLastError();
 }
 hipError_t cell_scatter(const CellArgs& a, hipStream_t st) {
-    cell_scatter_kernel<<<dim3((unsigned)((a.n_pad + kBucketBlock - 1) / kBucketBlock)), dim3(kBucketBlock), 0, st>>>(a);
+    cell_scatter_kernel<<<dim3((unsigned)((a.n_pad + kBucketBlock * kBucketChunks - 1) / (kBucketBlock * kBucketChunks))), dim3(kBucketBlock), 0, st>>>(a);
     return hipGetLastError();
 }
 
