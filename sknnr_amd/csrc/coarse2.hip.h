@@ -90,21 +90,23 @@ __host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb *
 #define SKNNR_V2_M2 1  // one neighbour (lists of 2) on the second-generation kernel, up to 32 features
 #endif
 #ifndef SKNNR_V2_M12
-#define SKNNR_V2_M12 1  // 16 .. 23 neighbours on pooled lists of 12 at ONE K-step, 16 waves (round 4: 98 -> 113 Mq/s at 16 features,
-                        // k = 20; at two K-steps the instance spills 20 registers and loses to lists of 16 at 12 waves, 65 vs 87 Mq/s)
+#define SKNNR_V2_M12 1  // 16 .. 23 neighbours on pooled lists of 12 (round 4), scripts/k16_probe.py, 2M x 50k rows: one K-step, 16 waves:
+                        // 98 -> 113 Mq/s at k = 20; two K-steps at 12 waves (at 16 the instance spills 20 registers: 65 Mq/s):
+                        // k = 16 / 20 / 23: 87 / 85 / 71 -> 89.5 / 90 / 77 Mq/s against lists of 16
 #endif
 #ifndef SKNNR_V2_M16
 #define SKNNR_V2_M16 1  // 8 .. 15 neighbours (lists of 16) on the second-generation kernel, up to 32 features, 12 waves
 #endif
 __host__ __device__ constexpr bool coarse2_supported(int ks, int m) {
     return (m == 6 && ks <= 4) || (m == 8 && ks <= 3) || (SKNNR_V2_M2 && m == 2 && ks <= 2) || (SKNNR_V2_M16 && m == 16 && ks <= 2) ||
-           (SKNNR_V2_M12 && m == 12 && ks <= 1);
+           (SKNNR_V2_M12 && m == 12 && ks <= 2);
 }
-// waves per workgroup of the bulk launch: 16 (4 per SIMD, <= 128 VGPRs); lists of 16 need 12 (3 per SIMD, <= 168)
+// waves per workgroup of the bulk launch: 16 (4 per SIMD, <= 128 VGPRs); lists of 16, and lists of 12 at two K-steps, need 12
+// (3 per SIMD, <= 168)
 #ifndef SKNNR_V2_M16_WAVES
 #define SKNNR_V2_M16_WAVES 12
 #endif
-__host__ __device__ constexpr int coarse2_waves(int ks, int m) { return m == 16 ? SKNNR_V2_M16_WAVES : kCoarse2Waves; }
+__host__ __device__ constexpr int coarse2_waves(int ks, int m) { return (m == 16 || (m == 12 && ks >= 2)) ? SKNNR_V2_M16_WAVES : kCoarse2Waves; }
 
 // sum_j x[j] * y[j] over one 8-element fragment, f32 accumulate (v_dot2c_f32_f16)
 __device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc) {

@@ -115,6 +115,7 @@ int coarse2_part1(int ks, int m, int waves, int extra, const Coarse2Launch& L, h
     if (ks == 2 && m == 8) return by_waves<2, 8>(waves, extra, L, st, err);
     if (ks == 3 && m == 8) return by_waves<3, 8>(waves, extra, L, st, err);
     if (ks == 1 && m == 12) return by_waves<1, 12>(waves, extra, L, st, err);
+    if (ks == 2 && m == 12) return by_waves<2, 12>(waves, extra, L, st, err);
     if (ks == 1 && m == 16) return by_waves<1, 16>(waves, extra, L, st, err);
     if (ks == 2 && m == 16) return by_waves<2, 16>(waves, extra, L, st, err);
 #endif

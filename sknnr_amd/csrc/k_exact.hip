@@ -87,7 +87,7 @@ hipError_t cell_scatter(const CellArgs& a, hipStream_t st) {
 hipError_t finalize(const FinalizeArgs& f, long n, hipStream_t st) {
     if (f.m_list <= 8) {
         finalize_kernel<8><<<dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), finalize_lds_bytes(8, f.s.d), st>>>(f);
-    } else if (f.m_list == 16) {
+    } else if (f.m_list <= 16) {  // (lists of 12 and 16: 32 lanes per query)
         finalize_kernel<16><<<dim3((unsigned)((n * 32 + 255) / 256)), dim3(256), finalize_lds_bytes(16, f.s.d), st>>>(f);
     } else {
         finalize_kernel<32><<<dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), finalize_lds_bytes(32, f.s.d), st>>>(f);
