@@ -95,18 +95,23 @@ __host__ __device__ constexpr int queue2_bytes_per_wave() { return kCoarse2Nqb *
                         // k = 16 / 20 / 23: 87 / 85 / 71 -> 89.5 / 90 / 77 Mq/s against lists of 16
 #endif
 #ifndef SKNNR_V2_M16
-#define SKNNR_V2_M16 1  // 8 .. 15 neighbours (lists of 16) on the second-generation kernel, up to 32 features, 12 waves
+#define SKNNR_V2_M16 1  // 16 .. 31 neighbours (lists of 16) on the second-generation kernel, 12 waves
 #endif
 __host__ __device__ constexpr bool coarse2_supported(int ks, int m) {
-    return (m == 6 && ks <= 4) || (m == 8 && ks <= 3) || (SKNNR_V2_M2 && m == 2 && ks <= 2) || (SKNNR_V2_M16 && m == 16 && ks <= 2) ||
-           (SKNNR_V2_M12 && m == 12 && ks <= 2);
+    return (m == 6 && ks <= 4) || (m == 8 && ks <= 4) || (SKNNR_V2_M2 && m == 2 && ks <= 2) || (SKNNR_V2_M16 && m == 16 && ks <= 4) ||
+           (SKNNR_V2_M12 && m == 12 && ks <= 4);
 }
-// waves per workgroup of the bulk launch: 16 (4 per SIMD, <= 128 VGPRs); lists of 16, and lists of 12 at two K-steps, need 12
-// (3 per SIMD, <= 168)
+// waves per workgroup of the bulk launch: 16 (4 per SIMD, <= 128 VGPRs); lists of 16, lists of 12 from two K-steps on and lists
+// of 8 at four K-steps need 12 (3 per SIMD, <= 168).  Round 4 (end): the three- and four-K-step instances of lists of 8 / 12 / 16
+// at 12 waves (6 .. 60 spilled registers) replace the first-generation kernel for 8 .. 31 neighbours at 33 .. 64 features:
+// scripts/wide_k_probe.py, 1M x 50k rows: k = 10 / 14 at 64 features 60.5 / 54 -> 79 / 69 Mq/s, k = 20 / 25 at 48 features
+// 32 / 30 -> 68.5 / 52, k = 20 / 30 at 64 features 32 / 27 -> 62 / 32
 #ifndef SKNNR_V2_M16_WAVES
 #define SKNNR_V2_M16_WAVES 12
 #endif
-__host__ __device__ constexpr int coarse2_waves(int ks, int m) { return (m == 16 || (m == 12 && ks >= 2)) ? SKNNR_V2_M16_WAVES : kCoarse2Waves; }
+__host__ __device__ constexpr int coarse2_waves(int ks, int m) {
+    return (m == 16 || (m == 12 && ks >= 2) || (m == 8 && ks >= 4)) ? SKNNR_V2_M16_WAVES : kCoarse2Waves;
+}
 
 // sum_j x[j] * y[j] over one 8-element fragment, f32 accumulate (v_dot2c_f32_f16)
 __device__ __forceinline__ float dot8(const half8& x, const half8& y, float acc) {

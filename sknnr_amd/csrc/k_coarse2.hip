@@ -1,6 +1,6 @@
 // k_coarse2.hip -- kernel translation unit: the second-generation MFMA pre-filter (coarse2.hip.h), one instance per
 // (K-steps, list length, waves per workgroup, rank beyond the list), behind launch.hip.h.  Compiled in two halves
-// (-DSKNNR_C2_PART=0: lists of 2 and 6; =1: lists of 8, 12 and 16) so that the halves build in parallel.
+// (-DSKNNR_C2_PART=0: lists of 2 and 6; =1: lists of 8, 12 and 16 at one to four K-steps) so that the halves build in parallel.
 #include <cstdio>
 #include <cstring>
 
@@ -114,6 +114,11 @@ int coarse2_part1(int ks, int m, int waves, int extra, const Coarse2Launch& L, h
     if (ks == 1 && m == 8) return by_waves<1, 8>(waves, extra, L, st, err);
     if (ks == 2 && m == 8) return by_waves<2, 8>(waves, extra, L, st, err);
     if (ks == 3 && m == 8) return by_waves<3, 8>(waves, extra, L, st, err);
+    if (ks == 4 && m == 8) return by_waves<4, 8>(waves, extra, L, st, err);
+    if (ks == 3 && m == 12) return by_waves<3, 12>(waves, extra, L, st, err);
+    if (ks == 3 && m == 16) return by_waves<3, 16>(waves, extra, L, st, err);
+    if (ks == 4 && m == 12) return by_waves<4, 12>(waves, extra, L, st, err);
+    if (ks == 4 && m == 16) return by_waves<4, 16>(waves, extra, L, st, err);
     if (ks == 1 && m == 12) return by_waves<1, 12>(waves, extra, L, st, err);
     if (ks == 2 && m == 12) return by_waves<2, 12>(waves, extra, L, st, err);
     if (ks == 1 && m == 16) return by_waves<1, 16>(waves, extra, L, st, err);

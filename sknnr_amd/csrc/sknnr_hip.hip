@@ -1312,7 +1312,7 @@ bool use_coarse2(const sknnr_index* ix, int m_list) {
 constexpr int kCoarseMaxKK = 31;
 int coarse_list_len(int kk) { return kk <= 1 ? 2 : (kk <= 5 ? 6 : (kk <= 7 ? 8 : (kk <= 15 ? 16 : 32))); }
 // ... for this handle: where the second-generation kernel serves them, 6 .. 7 neighbours keep lists of 6, 8 .. 15 lists of
-// 8, 16 .. 23 lists of 12 and 24 .. 31 lists of 16 (up to 32 features), with thresholds of a rank beyond one list over the two lists of a query kept as one pool
+// 8, 16 .. 23 lists of 12 and 24 .. 31 lists of 16 (up to 64 features), with thresholds of a rank beyond one list over the two lists of a query kept as one pool
 // (coarse2.hip.h, pair_union_rank, coarse2_rank_extra) -- shorter lists are cheaper to keep, lists of 8 run with 16 waves
 // per CU and no spills where lists of 16 need 12 waves, and lists of 32 exist on the first-generation kernel only.
 int coarse_list_len(const sknnr_index* ix, int kk) {

@@ -158,15 +158,16 @@ def test_ref_sharded_knn_class_single_rank(tmp_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d", [8, 32, 64])
+@pytest.mark.parametrize("d", [8, 32, 48, 64])
 def test_more_neighbours_than_a_list_holds_on_pooled_lists(N, d):
     """k + self = 6 .. 7 on lists of 6, 8 .. 15 on lists of 8, 16 .. 23 on lists of 12 (d = 8: 16 waves, d = 32: 12 waves), 24 .. 31
     on lists of 16 (second-generation pre-filter):
     thresholds of a rank beyond one list over the two lists of a query kept as one pool (coarse2.hip.h, pair_union_rank,
     coarse2_rank_extra).  A query with more of its neighbours in one lane's half of the rows than that lane's list holds
     (about one in forty at 16 of 22) goes through the hand-over between the lists.  8,000 reference rows (v2 needs 4,096),
-    some duplicated (ties across the k-th slot), 6,000 query rows, X=None too.  64 features: lists of 6 only (four K-steps),
-    the others stay on the first-generation kernel."""
+    some duplicated (ties across the k-th slot), 6,000 query rows, X=None too.  48 and 64 features: the three- and four-K-step
+    instances (12 waves per workgroup from lists of 8 at four K-steps on; round 4 -- the first-generation kernel before).
+    """
     from oracle import oracle as O
     from sknnr_amd import synth
 
